@@ -1,0 +1,126 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+//
+// C-ABI shim around the *unmodified* reference sources, compiled where they lie under
+// /root/reference by oracle/Makefile into oracle/_ref/libgamref.so (git-ignored).
+// It exists so that (1) oracle/gamdp_oracle.c can be pinned against the real reference and
+// (2) tests/golden/make_golden.py can generate the committed golden vectors.
+//
+// Reference entry points wrapped here:
+//   BandedSmithWaterman::find_alignment   lib/src/alignment/banded_smith_waterman.cc:69-322
+//   first_match_pos / last_match_pos      lib/src/alignment/my_alignment.cc:167-193, 228-262
+//   ABlast::findHits                      lib/src/alignment/ablast.cc:41-76
+//   reverse_complement / chop_begin       lib/include/assembly/contig.code.hpp:187-229, 257-261
+//   Nucleotide(char)                      lib/include/assembly/nucleotide.code.hpp:47-75
+#include <cstdint>
+#include <cstring>
+#include <list>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "alignment/ablast.hpp"
+#include "alignment/banded_smith_waterman.hpp"
+#include "alignment/my_alignment.hpp"
+#include "assembly/contig.hpp"
+
+extern "C" {
+
+struct gamref_result {
+    uint64_t begin_a, begin_b;
+    uint64_t a_size, b_size;
+    int64_t score;
+    double homology;
+    uint64_t length;
+    uint64_t n_match;
+    uint64_t first_a, first_b;
+    uint64_t last_a, last_b;
+    int32_t first_found, last_found;
+    int32_t status;  // 0 ok, 2 = reference threw std::out_of_range, 3 = other exception
+};
+
+static Contig make_contig(const char* s, uint64_t n)
+{
+    Contig c(std::string("c"), size_t(n));
+    for (uint64_t i = 0; i < n; i++) c.at(i) = s[i];  // Nucleotide::operator=(char)
+    return c;
+}
+
+static void summarise(const MyAlignment& r, gamref_result* out, uint8_t* ops, uint64_t ops_cap)
+{
+    out->begin_a = r.begin_a();
+    out->begin_b = r.begin_b();
+    out->a_size = r.a_size();
+    out->b_size = r.b_size();
+    out->score = r.score();
+    out->homology = r.homology();
+    out->length = r.length();
+    uint64_t nm = 0;
+    for (uint64_t i = 0; i < r.sequence().size(); i++) {
+        if (r.sequence()[i] == MATCH) nm++;
+        if (ops && i < ops_cap) ops[i] = uint8_t(r.sequence()[i]);
+    }
+    out->n_match = nm;
+    std::pair<uint64_t, uint64_t> p;
+    out->first_found = first_match_pos(r, p) ? 1 : 0;
+    out->first_a = p.first;
+    out->first_b = p.second;
+    out->last_found = last_match_pos(r, p) ? 1 : 0;
+    out->last_a = p.first;
+    out->last_b = p.second;
+}
+
+int gamref_find_alignment(const char* a, uint64_t alen, const char* b, uint64_t blen, uint64_t band,
+                          uint64_t begin_a, uint64_t end_a, uint64_t begin_b, uint64_t end_b,
+                          int force_start, int force_end, gamref_result* out, uint8_t* ops,
+                          uint64_t ops_cap)
+{
+    std::memset(out, 0, sizeof(*out));
+    try {
+        Contig ca = make_contig(a, alen), cb = make_contig(b, blen);
+        BandedSmithWaterman bsw{BandedSmithWaterman::size_type(band)};
+        MyAlignment r = bsw.find_alignment(ca, begin_a, end_a, cb, begin_b, end_b, force_start != 0,
+                                           force_end != 0);
+        summarise(r, out, ops, ops_cap);
+        out->status = 0;
+    } catch (const std::out_of_range&) {
+        out->status = 2;
+    } catch (...) {
+        out->status = 3;
+    }
+    return out->status;
+}
+
+// returns number of hits (may exceed cap; only the first cap are written)
+int64_t gamref_find_hits(const char* a, uint64_t alen, uint64_t a_start, uint64_t a_end,
+                         const char* b, uint64_t blen, uint64_t b_start, uint64_t b_end,
+                         uint64_t word, uint32_t* hits, uint64_t cap)
+{
+    try {
+        Contig ca = make_contig(a, alen), cb = make_contig(b, blen);
+        ABlast ab{size_t(word)};
+        std::list<uint32_t> h = ab.findHits(ca, a_start, a_end, cb, b_start, b_end);
+        uint64_t k = 0;
+        for (std::list<uint32_t>::const_iterator it = h.begin(); it != h.end(); ++it, ++k)
+            if (k < cap) hits[k] = *it;
+        return int64_t(h.size());
+    } catch (...) {
+        return -1;
+    }
+}
+
+// in-place reverse complement through the reference's Contig functions; writes ACGTN chars
+void gamref_reverse_complement(char* s, uint64_t n)
+{
+    Contig c = make_contig(s, n);
+    reverse_complement(c);
+    for (uint64_t i = 0; i < n; i++) s[i] = char(c.at(i));
+}
+
+// normalise chars exactly as the reference's loader does (acgtn any case, everything else -> N)
+void gamref_normalise(char* s, uint64_t n)
+{
+    Contig c = make_contig(s, n);
+    for (uint64_t i = 0; i < n; i++) s[i] = char(c.at(i));
+}
+
+}  // extern "C"
