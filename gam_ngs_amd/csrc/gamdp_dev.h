@@ -1,0 +1,78 @@
+// Structures shared between the host side of libgamdp (gamdp_host.cpp) and the gfx950 kernels
+// (gamdp_kernel.hip).  Internal -- the public boundary is include/gamdp.h.
+#pragma once
+#include <stdint.h>
+
+namespace gamdp {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// Sequence planes in HBM (one buffer per seqset):
+//   2-bit plane: 16 bases per u32, base i at bits [2*(i&15)+1 : 2*(i&15)], codes A=0 T=1 C=2 G=3,
+//                N stored as 0;
+//   N plane:     32 bases per u32, bit (i&31) set when base i is N.
+// Every sequence is preceded and followed by SEQ_PAD_BASES zero bases so that the kernels' window
+// fetches (which run up to band+64*17 bases outside the contig) never leave the allocation.
+constexpr int SEQ_PAD_BASES = 4096;
+
+// one find_alignment call, pre-validated and pre-sized on the host
+struct DevTask {
+    const u32* a2;  // word holding base 0 of sequence a (2-bit plane)
+    const u32* an;  // word holding base 0 of sequence a (N plane)
+    const u32* b2;
+    const u32* bn;
+    int64_t a_base;  // view offset (chop_begin) in bases
+    int64_t b_base;
+    int64_t end_a;   // clamped to [0, 2^40]
+    int32_t alen, blen;  // view lengths
+    int32_t begin_a, begin_b;
+    int32_t X;       // rows of the band matrix (x_size)
+    int32_t band;
+    u32 flags;       // TF_*
+    u32 res_idx;     // slot in the result array
+    u64 ops_off;     // where this task's ops go in the ops buffer (traceback order, i.e. reversed)
+    u64 ops_cap;
+};
+
+enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4 };
+
+struct DevResult {
+    int32_t begin_a, begin_b;
+    int32_t score;
+    u32 n_match, length;
+    int32_t first_a, first_b, last_a, last_b;
+    u32 flags;  // bit0 first_found, bit1 last_found, bits 8.. status (GAMDP_ST_*)
+};
+
+// one kernel launch = one group of tasks that share (band, N-awareness) and a scratch slot size
+struct LaunchParams {
+    const DevTask* tasks;  // sorted by decreasing cell count
+    u32 n_tasks;
+    u32* cursor;           // work-queue head (zeroed before the launch)
+    DevResult* results;
+    uint8_t* ops_buf;
+    u32* scratch;          // n_slots * slot_words
+    u64 slot_words;        // u32 words per slot
+    u64 dir_words;         // direction words at the start of a slot; side buffers follow
+    u32 ypad;              // side-buffer stride in words (>= 2*band+2)
+};
+
+// Kernel variants.  C = band columns per lane; CE = (2*band) % C is the in-lane position of the
+// last band column (compile-time for the tuned variants, -1 = runtime for the generic ones).
+enum KernelId : int {
+    K_C17_CE4 = 0,   // band 512 (benchmark workload), ACGT only
+    K_C17_CE4_N,     // band 512, N-aware
+    K_C5_CE0,        // band 150 (gam-merge's live default), ACGT only
+    K_C5_CE0_N,      // band 150, N-aware
+    K_GEN_C2, K_GEN_C3, K_GEN_C5, K_GEN_C9, K_GEN_C17,  // any band, N-aware, runtime edge column
+    K_COUNT
+};
+
+int kernel_cols(int kid);
+// launches on `stream`; returns hipError_t as int
+int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream);
+// occupancy hint: resident waves per CU for this variant
+int kernel_waves_per_cu(int kid);
+
+}  // namespace gamdp

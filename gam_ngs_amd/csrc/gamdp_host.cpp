@@ -1,0 +1,572 @@
+// Host side of libgamdp (C ABI in include/gamdp.h): contexts, packed sequence sets, the L0 batch
+// launcher and the small host functions on the path (encode / revcomp / findHits / synthetic pairs).
+// The merge-block chain driver (L1) lives in gamdp_l1.cpp.
+//
+// There is deliberately no CPU implementation of the DP here: every alignment goes through the
+// gfx950 kernels in gamdp_kernel.hip, and context creation fails without a GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gamdp.h"
+#include "gamdp_dev.h"
+#include "gamdp_internal.h"
+
+namespace gamdp {
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+            return GAMDP_EHIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+// ---- sequence packing ---------------------------------------------------------------------------
+
+static inline uint8_t encode_char(char ch)
+{  // Nucleotide(char), nucleotide.code.hpp:47-75
+    switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'T': case 't': return 1;
+    case 'C': case 'c': return 2;
+    case 'G': case 'g': return 3;
+    default: return 4;
+    }
+}
+
+// words needed for one padded sequence in each plane (rounded so every sequence starts 64-base aligned)
+static inline u64 padded_bases(u64 len) { return ((len + 2 * (u64)SEQ_PAD_BASES + 63) / 64) * 64 + 64; }
+
+// pack codes[0..len) into plane2/planeN starting at base offset `at` (a multiple of 32)
+static void pack_into(const uint8_t* codes, u64 len, bool rc, u32* plane2, u32* planeN, u64 at)
+{
+    static const uint8_t comp[5] = {1, 0, 3, 2, 4};
+    for (u64 i = 0; i < len; i++) {
+        uint8_t c = rc ? comp[codes[len - 1 - i] > 4 ? 4 : codes[len - 1 - i]] : codes[i];
+        if (c > 4) c = 4;
+        const u64 k = at + i;
+        if (c == 4) planeN[k >> 5] |= 1u << (k & 31);
+        else plane2[k >> 4] |= (u32)c << ((k & 15) * 2);
+    }
+}
+
+int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, bool ascii)
+{
+    ctx = ctx_;
+    codes.resize(n);
+    fwd.resize(n);
+    rc.assign(n, DevSeq{nullptr, nullptr});
+    has_n.assign(n, 0);
+    u64 total = 0;
+    std::vector<u64> at(n);
+    for (u32 i = 0; i < n; i++) {
+        if (lens[i] >= (1ull << 31) - 3 * (u64)SEQ_PAD_BASES) return GAMDP_EINVAL;
+        at[i] = total + SEQ_PAD_BASES;  // total stays a multiple of 64
+        total += padded_bases(lens[i]);
+    }
+    std::vector<u32> h2(total / 16 + 4, 0), hn(total / 32 + 4, 0);
+    for (u32 i = 0; i < n; i++) {
+        codes[i].resize(lens[i]);
+        bool anyn = false;
+        for (u64 k = 0; k < lens[i]; k++) {
+            uint8_t c = ascii ? encode_char((char)seqs[i][k]) : (seqs[i][k] > 4 ? (uint8_t)4 : seqs[i][k]);
+            codes[i][k] = c;
+            anyn |= (c == 4);
+        }
+        has_n[i] = anyn;
+        pack_into(codes[i].data(), lens[i], false, h2.data(), hn.data(), at[i]);
+    }
+    HIPCHK(ctx, hipMalloc(&d2, h2.size() * sizeof(u32)));
+    HIPCHK(ctx, hipMalloc(&dn, hn.size() * sizeof(u32)));
+    HIPCHK(ctx, hipMemcpyAsync(d2, h2.data(), h2.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dn, hn.data(), hn.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (u32 i = 0; i < n; i++) fwd[i] = DevSeq{d2 + at[i] / 16, dn + at[i] / 32};
+    return 0;
+}
+
+// make sure reverse-complement copies exist on the device for the listed sequence ids
+int SeqSet::ensure_rc(const std::vector<u32>& ids) const
+{
+    std::vector<u32> todo;
+    for (u32 id : ids)
+        if (!rc[id].p2 && std::find(todo.begin(), todo.end(), id) == todo.end()) todo.push_back(id);
+    if (todo.empty()) return 0;
+    u64 total = 0;
+    std::vector<u64> at(todo.size());
+    for (size_t k = 0; k < todo.size(); k++) {
+        at[k] = total + SEQ_PAD_BASES;
+        total += padded_bases(codes[todo[k]].size());
+    }
+    std::vector<u32> h2(total / 16 + 4, 0), hn(total / 32 + 4, 0);
+    for (size_t k = 0; k < todo.size(); k++)
+        pack_into(codes[todo[k]].data(), codes[todo[k]].size(), true, h2.data(), hn.data(), at[k]);
+    u32 *p2 = nullptr, *pn = nullptr;
+    HIPCHK(ctx, hipMalloc(&p2, h2.size() * sizeof(u32)));
+    HIPCHK(ctx, hipMalloc(&pn, hn.size() * sizeof(u32)));
+    rc_allocs.push_back(p2);
+    rc_allocs.push_back(pn);
+    HIPCHK(ctx, hipMemcpyAsync(p2, h2.data(), h2.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pn, hn.data(), hn.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < todo.size(); k++) rc[todo[k]] = DevSeq{p2 + at[k] / 16, pn + at[k] / 32};
+    return 0;
+}
+
+SeqSet::~SeqSet()
+{
+    if (d2) (void)hipFree(d2);
+    if (dn) (void)hipFree(dn);
+    for (u32* p : rc_allocs) (void)hipFree(p);
+}
+
+// ---- context ------------------------------------------------------------------------------------
+
+int Ctx::init(int dev)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || dev < 0 || dev >= ndev) {
+        set_error("no usable HIP device");
+        return GAMDP_ENODEV;
+    }
+    device = dev;
+    if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice failed"); return GAMDP_ENODEV; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return GAMDP_ENODEV; }
+    n_cu = prop.multiProcessorCount;
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", libgamdp is built for gfx950 only");
+        return GAMDP_ENODEV;
+    }
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return GAMDP_ENODEV; }
+    if (hipMalloc(&d_cursor, 64 * sizeof(u32)) != hipSuccess) { set_error("hipMalloc failed"); return GAMDP_ENOMEM; }
+    return 0;
+}
+
+Ctx::~Ctx()
+{
+    if (device >= 0) (void)hipSetDevice(device);
+    for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (d_tasks) (void)hipFree(d_tasks);
+    if (d_results) (void)hipFree(d_results);
+    if (d_ops) (void)hipFree(d_ops);
+    if (d_cursor) (void)hipFree(d_cursor);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+template <class T>
+static int grow(Ctx* ctx, T*& ptr, u64& cap, u64 need)
+{
+    if (need <= cap) return 0;
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    u64 want = need + need / 4;
+    if (hipMalloc(&ptr, want * sizeof(T)) != hipSuccess) {
+        if (hipMalloc(&ptr, need * sizeof(T)) != hipSuccess) {
+            ctx->set_error("hipMalloc of " + std::to_string(need * sizeof(T)) + " bytes failed");
+            return GAMDP_ENOMEM;
+        }
+        want = need;
+    }
+    cap = want;
+    return 0;
+}
+
+// ---- task validation (same order as banded_smith_waterman.cc:90-132) -------------------------------
+
+static int pick_kernel(int band, bool has_n)
+{
+    if (band == 512) return has_n ? K_C17_CE4_N : K_C17_CE4;
+    if (band == 150) return has_n ? K_C5_CE0_N : K_C5_CE0;
+    const int Y = 2 * band + 1;
+    if (Y <= 2 * 64) return K_GEN_C2;
+    if (Y <= 3 * 64) return K_GEN_C3;
+    if (Y <= 5 * 64) return K_GEN_C5;
+    if (Y <= 9 * 64) return K_GEN_C9;
+    return K_GEN_C17;
+}
+
+struct Prepared {
+    DevTask dt;
+    int kid;
+    u64 cells;
+    u64 dir_words;
+};
+
+// returns GAMDP_ST_OK when the task has to run on the GPU, otherwise its final status
+static int prepare_task(const ITask& it, Prepared& pr)
+{
+    const u64 alen_full = it.sa->codes[it.a_id].size(), blen_full = it.sb->codes[it.b_id].size();
+    if (it.a_off > alen_full || it.b_off > blen_full) return GAMDP_ST_INVALID;
+    const u64 alen = alen_full - it.a_off, blen = blen_full - it.b_off;
+    const u64 band = it.band;
+    u64 begin_a = it.begin_a, end_a = it.end_a, begin_b = it.begin_b, end_b = it.end_b;
+    const bool fs = it.force_start, fe = it.force_end;
+    pr.cells = 0;
+    if (end_b < begin_b) return GAMDP_ST_EMPTY;                       // :90
+    if (begin_a >= (1ull << 31) - 65536) return GAMDP_ST_INVALID;     // beyond any contig this code addresses
+    const int64_t lo = std::max<int64_t>(0, (int64_t)begin_a - (int64_t)band), hi = (int64_t)begin_a + (int64_t)band;
+    if (begin_b >= blen) {
+        // b.at(begin_b) / a.at(pos) throws in the row-0 loop once a column qualifies (:116-131)
+        bool any;
+        if (!fs) any = lo < (int64_t)alen;                            // some 0 <= pos < |a| in the band
+        else any = (lo <= std::min<int64_t>(hi, FORCE_MAXGAP_)) || lo < (int64_t)alen;
+        return any ? GAMDP_ST_OUT_OF_RANGE : GAMDP_ST_INVALID;
+    }
+    if (end_b >= blen) end_b = blen - 1;                              // :91
+    u64 X = end_b - begin_b + 1;                                      // :93-95
+    const u64 lim = alen + band - begin_a;                            // unsigned wrap as in the reference
+    if (lim < X) X = lim;
+    if (X > 500000) X = 500000;
+    if (X == 0) return GAMDP_ST_INVALID;
+    const u64 Y = 2 * band + 1;
+    pr.cells = X * Y;
+    if (fs) {  // row 0 touches a.at(pos) for every 0 <= pos <= 10 in the band, even past |a| (:116)
+        const int64_t up = std::min<int64_t>(hi, FORCE_MAXGAP_);
+        if (lo <= up && up >= (int64_t)alen) return GAMDP_ST_OUT_OF_RANGE;
+    }
+    const bool has_n = it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
+    pr.kid = pick_kernel((int)band, has_n);
+    const int C = kernel_cols(pr.kid);
+    const int LE = (int)((Y - 1) / (u64)C);
+    const u64 nblk = (X - 1 + (u64)LE) / 16 + 1;
+    pr.dir_words = nblk * (u64)C * 64;
+    DevTask& d = pr.dt;
+    const DevSeq& da = it.a_rc ? it.sa->rc[it.a_id] : it.sa->fwd[it.a_id];
+    const DevSeq& db = it.b_rc ? it.sb->rc[it.b_id] : it.sb->fwd[it.b_id];
+    d.a2 = da.p2; d.an = da.pn; d.b2 = db.p2; d.bn = db.pn;
+    d.a_base = (int64_t)it.a_off; d.b_base = (int64_t)it.b_off;
+    d.end_a = (int64_t)std::min<u64>(end_a, 1ull << 40);
+    d.alen = (int32_t)alen; d.blen = (int32_t)blen;
+    d.begin_a = (int32_t)begin_a; d.begin_b = (int32_t)begin_b;
+    d.X = (int32_t)X; d.band = (int32_t)band;
+    d.flags = (fs ? TF_FORCE_START : 0u) | (fe ? TF_FORCE_END : 0u);
+    d.ops_off = 0; d.ops_cap = 0;
+    return GAMDP_ST_OK;
+}
+
+static void fill_result(const DevResult& r, u64 cells, gamdp_result& o)
+{
+    std::memset(&o, 0, sizeof(o));
+    o.status = (uint8_t)(r.flags >> 8);
+    o.cells = cells;
+    if (o.status != GAMDP_ST_OK) return;
+    o.begin_a = (u64)(int64_t)r.begin_a; o.begin_b = (u64)(int64_t)r.begin_b;
+    o.score = r.score;
+    o.n_match = r.n_match; o.length = r.length;
+    o.first_a = (u64)(int64_t)r.first_a; o.first_b = (u64)(int64_t)r.first_b;
+    o.last_a = (u64)(int64_t)r.last_a; o.last_b = (u64)(int64_t)r.last_b;
+    o.first_found = r.flags & 1u; o.last_found = (r.flags >> 1) & 1u;
+    o.homology = o.length ? (double)(o.n_match * 100) / (double)o.length : 0.0;  // :319
+}
+
+// ---- L0 batch -----------------------------------------------------------------------------------
+
+int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops)
+{
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return GAMDP_EHIP; }
+    const size_t n = tasks.size();
+    if (n == 0) return 0;
+    // reverse complements needed by this batch
+    {
+        std::vector<std::pair<const SeqSet*, std::vector<u32>>> need;
+        auto add = [&](const SeqSet* s, u32 id) {
+            for (auto& p : need) if (p.first == s) { p.second.push_back(id); return; }
+            need.push_back({s, {id}});
+        };
+        for (const ITask& t : tasks) {
+            if (t.band > GAMDP_MAX_BAND) { set_error("band " + std::to_string(t.band) + " exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
+            if (t.a_id >= t.sa->codes.size() || t.b_id >= t.sb->codes.size()) { set_error("sequence id out of range"); return GAMDP_EINVAL; }
+            if (t.a_rc) add(t.sa, t.a_id);
+            if (t.b_rc) add(t.sb, t.b_id);
+        }
+        for (auto& p : need) { int rc_ = p.first->ensure_rc(p.second); if (rc_) return rc_; }
+    }
+
+    std::vector<Prepared> prep(n);
+    std::vector<std::vector<u32>> groups(K_COUNT);
+    u64 ops_total = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int st = prepare_task(tasks[i], prep[i]);
+        if (st != GAMDP_ST_OK) {
+            std::memset(&out[i], 0, sizeof(out[i]));
+            out[i].status = (uint8_t)st;
+            out[i].cells = (st == GAMDP_ST_OUT_OF_RANGE) ? prep[i].cells : 0;
+            continue;
+        }
+        prep[i].dt.res_idx = (u32)i;
+        if (ops && ops->ops_buf && ops->ops_cap[i] > 0) {
+            prep[i].dt.flags |= TF_WANT_OPS;
+            prep[i].dt.ops_off = ops_total;
+            prep[i].dt.ops_cap = ops->ops_cap[i];
+            ops_total += ops->ops_cap[i];
+        }
+        groups[prep[i].kid].push_back((u32)i);
+    }
+
+    int rc_ = grow(this, d_results, cap_results, n);
+    if (rc_) return rc_;
+    if (ops_total) { rc_ = grow(this, d_ops, cap_ops, ops_total); if (rc_) return rc_; }
+    rc_ = grow(this, d_tasks, cap_tasks, n);
+    if (rc_) return rc_;
+
+    // arena budget
+    if (arena_limit == 0) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(this, hipMemGetInfo(&fr, &tot));
+        arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.6);
+    }
+
+    std::vector<DevTask> hostTasks;
+    hostTasks.reserve(n);
+    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; };
+    std::vector<Launch> launches;
+    const u32 max_resident = (u32)n_cu * 16u;
+    for (int kid = 0; kid < K_COUNT; kid++) {
+        auto& g = groups[kid];
+        if (g.empty()) continue;
+        std::sort(g.begin(), g.end(), [&](u32 x, u32 y) {
+            if (prep[x].cells != prep[y].cells) return prep[x].cells > prep[y].cells;
+            return x < y;
+        });
+        // split the group so that slots sized for its largest task fit the arena
+        size_t pos = 0;
+        while (pos < g.size()) {
+            u32 maxband = 0;
+            for (size_t k = pos; k < g.size(); k++) maxband = std::max<u32>(maxband, (u32)prep[g[k]].dt.band);
+            const u32 ypad = ((2 * maxband + 2 + 63) / 64) * 64;
+            const u64 dirw = ((prep[g[pos]].dir_words + 63) / 64) * 64;  // largest first
+            const u64 slotw = dirw + 4ull * ypad;
+            u64 fit = arena_limit / (slotw * sizeof(u32));
+            if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
+            // tasks much smaller than the head of the list get their own launch (smaller slots, more of them)
+            size_t end = pos;
+            while (end < g.size() && (end - pos < 64 || prep[g[end]].dir_words * 4 >= prep[g[pos]].dir_words)) end++;
+            Launch L;
+            L.kid = kid; L.first = (u32)hostTasks.size(); L.count = (u32)(end - pos);
+            L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
+            L.n_slots = (u32)std::min<u64>(std::min<u64>(L.count, max_resident), fit);
+            for (size_t k = pos; k < end; k++) hostTasks.push_back(prep[g[k]].dt);
+            launches.push_back(L);
+            pos = end;
+        }
+    }
+    if (!launches.empty()) {
+        u64 need_scratch = 0;
+        for (auto& L : launches) need_scratch = std::max(need_scratch, L.slot_words * L.n_slots);
+        if (need_scratch > cap_scratch) {
+            if (d_scratch) { (void)hipFree(d_scratch); d_scratch = nullptr; cap_scratch = 0; }
+            if (hipMalloc(&d_scratch, need_scratch * sizeof(u32)) != hipSuccess) {
+                set_error("hipMalloc of scratch arena (" + std::to_string(need_scratch * sizeof(u32)) + " bytes) failed");
+                return GAMDP_ENOMEM;
+            }
+            cap_scratch = need_scratch;
+        }
+        if (launches.size() > 64) {
+            // cursors: one u32 per launch
+            if (d_cursor) (void)hipFree(d_cursor);
+            d_cursor = nullptr;
+            HIPCHK(this, hipMalloc(&d_cursor, launches.size() * sizeof(u32)));
+        }
+        HIPCHK(this, hipMemcpyAsync(d_tasks, hostTasks.data(), hostTasks.size() * sizeof(DevTask), hipMemcpyHostToDevice, stream));
+        HIPCHK(this, hipMemsetAsync(d_cursor, 0, std::max<size_t>(64, launches.size()) * sizeof(u32), stream));
+        while (events.size() < launches.size()) {
+            hipEvent_t a, b;
+            HIPCHK(this, hipEventCreate(&a));
+            HIPCHK(this, hipEventCreate(&b));
+            events.push_back({a, b});
+        }
+        for (size_t li = 0; li < launches.size(); li++) {
+            const Launch& L = launches[li];
+            LaunchParams p;
+            p.tasks = d_tasks + L.first; p.n_tasks = L.count; p.cursor = d_cursor + li;
+            p.results = d_results; p.ops_buf = d_ops;
+            p.scratch = d_scratch; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
+            HIPCHK(this, hipEventRecord(events[li].first, stream));
+            const int e = launch_align(L.kid, p, L.n_slots, stream);
+            if (e != 0) { set_error(std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)e)); return GAMDP_EHIP; }
+            HIPCHK(this, hipEventRecord(events[li].second, stream));
+        }
+        std::vector<DevResult> hres(n);
+        HIPCHK(this, hipMemcpyAsync(hres.data(), d_results, n * sizeof(DevResult), hipMemcpyDeviceToHost, stream));
+        std::vector<uint8_t> hops(ops_total);
+        if (ops_total) HIPCHK(this, hipMemcpyAsync(hops.data(), d_ops, ops_total, hipMemcpyDeviceToHost, stream));
+        HIPCHK(this, hipStreamSynchronize(stream));
+        for (size_t li = 0; li < launches.size(); li++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
+        }
+        for (const DevTask& d : hostTasks) {
+            const u32 i = d.res_idx;
+            fill_result(hres[i], prep[i].cells, out[i]);
+            if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
+                const u64 len = std::min<u64>(out[i].length, d.ops_cap);
+                // the kernel wrote ops in traceback order: reverse into the caller's buffer
+                uint8_t* dst = ops->ops_buf + ops->ops_off[i];
+                const uint8_t* src = hops.data() + d.ops_off;
+                if (out[i].length <= d.ops_cap) for (u64 k = 0; k < len; k++) dst[k] = src[len - 1 - k];
+                else for (u64 k = 0; k < len; k++) dst[k] = 0xFF;  // truncated: not reconstructible
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace gamdp
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+using namespace gamdp;
+
+extern "C" {
+
+int gamdp_ctx_create(int device, gamdp_ctx** out)
+{
+    if (!out) return GAMDP_EINVAL;
+    *out = nullptr;
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) return GAMDP_ENOMEM;
+    const int rc_ = c->init(device);
+    if (rc_) {
+        std::fprintf(stderr, "libgamdp: %s\n", c->err.c_str());
+        delete c;
+        return rc_;
+    }
+    *out = reinterpret_cast<gamdp_ctx*>(c);
+    return 0;
+}
+
+void gamdp_ctx_destroy(gamdp_ctx* ctx) { delete reinterpret_cast<Ctx*>(ctx); }
+
+int gamdp_ctx_set_arena_bytes(gamdp_ctx* ctx, uint64_t bytes)
+{
+    if (!ctx) return GAMDP_EINVAL;
+    reinterpret_cast<Ctx*>(ctx)->arena_limit = bytes;
+    return 0;
+}
+
+const char* gamdp_last_error(const gamdp_ctx* ctx) { return ctx ? reinterpret_cast<const Ctx*>(ctx)->err.c_str() : "null ctx"; }
+
+void* gamdp_ctx_stream(gamdp_ctx* ctx) { return ctx ? (void*)reinterpret_cast<Ctx*>(ctx)->stream : nullptr; }
+
+int gamdp_ctx_kernel_time(gamdp_ctx* ctx, double* total_ms, uint64_t* launches, int reset)
+{
+    if (!ctx) return GAMDP_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (total_ms) *total_ms = c->kernel_ms;
+    if (launches) *launches = c->kernel_launches;
+    if (reset) { c->kernel_ms = 0; c->kernel_launches = 0; }
+    return 0;
+}
+
+int gamdp_seqset_create(gamdp_ctx* ctx, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, int is_ascii,
+                        gamdp_seqset** out)
+{
+    if (!ctx || !out || (n && (!seqs || !lens))) return GAMDP_EINVAL;
+    *out = nullptr;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (hipSetDevice(c->device) != hipSuccess) return GAMDP_EHIP;
+    SeqSet* s = new (std::nothrow) SeqSet();
+    if (!s) return GAMDP_ENOMEM;
+    const int rc_ = s->upload(c, seqs, lens, n, is_ascii != 0);
+    if (rc_) { delete s; return rc_; }
+    *out = reinterpret_cast<gamdp_seqset*>(s);
+    return 0;
+}
+
+void gamdp_seqset_destroy(gamdp_seqset* set)
+{
+    SeqSet* s = reinterpret_cast<SeqSet*>(set);
+    if (s && s->ctx) (void)hipSetDevice(s->ctx->device);
+    delete s;
+}
+
+uint32_t gamdp_seqset_size(const gamdp_seqset* set) { return set ? (uint32_t)reinterpret_cast<const SeqSet*>(set)->codes.size() : 0; }
+
+uint64_t gamdp_seqset_length(const gamdp_seqset* set, uint32_t id)
+{
+    const SeqSet* s = reinterpret_cast<const SeqSet*>(set);
+    return (s && id < s->codes.size()) ? s->codes[id].size() : 0;
+}
+
+int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seqset* set_b, const gamdp_task* tasks,
+                      size_t n, gamdp_result* out, const gamdp_ops* ops)
+{
+    if (!ctx || !set_a || !set_b || (n && (!tasks || !out))) return GAMDP_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    const SeqSet* sa = reinterpret_cast<const SeqSet*>(set_a);
+    const SeqSet* sb = reinterpret_cast<const SeqSet*>(set_b);
+    std::vector<ITask> it(n);
+    for (size_t i = 0; i < n; i++) {
+        const gamdp_task& t = tasks[i];
+        it[i] = ITask{sa, sb, t.a_id, t.b_id, t.a_off, t.b_off, t.a_rc != 0, t.b_rc != 0, t.force_start != 0,
+                      t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
+    }
+    return c->align(it, out, ops);
+}
+
+void gamdp_encode(const char* chars, uint64_t n, uint8_t* codes)
+{
+    for (uint64_t i = 0; i < n; i++) codes[i] = encode_char(chars[i]);
+}
+
+void gamdp_decode(const uint8_t* codes, uint64_t n, char* chars)
+{  // operator char(), nucleotide.code.hpp:111-126
+    static const char L[5] = {'A', 'T', 'C', 'G', 'N'};
+    for (uint64_t i = 0; i < n; i++) chars[i] = L[codes[i] > 4 ? 4 : codes[i]];
+}
+
+void gamdp_revcomp(uint8_t* codes, uint64_t n)
+{  // complement then reverse, contig.code.hpp:187-229
+    static const uint8_t comp[5] = {1, 0, 3, 2, 4};
+    for (uint64_t i = 0; i < n / 2; i++) {
+        const uint8_t x = comp[codes[i] > 4 ? 4 : codes[i]], y = comp[codes[n - 1 - i] > 4 ? 4 : codes[n - 1 - i]];
+        codes[i] = y;
+        codes[n - 1 - i] = x;
+    }
+    if (n & 1) codes[n / 2] = comp[codes[n / 2] > 4 ? 4 : codes[n / 2]];
+}
+
+int64_t gamdp_find_hits(const uint8_t* a, uint64_t alen, uint64_t a_start, uint64_t a_end, const uint8_t* b, uint64_t blen,
+                        uint64_t b_start, uint64_t b_end, uint64_t word, uint32_t* hits, uint64_t cap)
+{
+    std::vector<uint32_t> h;
+    find_hits(a, alen, a_start, a_end, b, blen, b_start, b_end, word, h);
+    for (size_t i = 0; i < h.size() && i < cap && hits; i++) hits[i] = h[i];
+    return (int64_t)h.size();
+}
+
+uint64_t gamdp_synth_pair(uint64_t k, uint64_t len, uint8_t* master, uint8_t* slave)
+{
+    // splitmix64 stream keyed by k; see SURVEY.md section 8(d) for the workload definition
+    uint64_t s = 0x47414DULL + k * 0xD1B54A32D192ED03ULL;
+    auto next = [&s]() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    };
+    (void)next();
+    for (uint64_t i = 0; i < len; i++) master[i] = (uint8_t)(next() >> 62);
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < len; i++) {
+        const uint64_t r = next(), u = r >> 40;
+        if (u >= 167772) {                       // 1 % deletion below this
+            uint8_t base = master[i];
+            if (u < 671088) base = (uint8_t)((base + 1 + (r & 0xFFFF) % 3) & 3);  // 3 % substitution
+            slave[n++] = base;
+        }
+        const uint64_t r2 = next();
+        if ((r2 >> 40) < 167772) slave[n++] = (uint8_t)(r2 & 3);                 // 1 % insertion
+    }
+    return n;
+}
+
+}  // extern "C"

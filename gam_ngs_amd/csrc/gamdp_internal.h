@@ -1,0 +1,77 @@
+// Host-internal types of libgamdp (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gamdp.h"
+#include "gamdp_dev.h"
+
+namespace gamdp {
+
+constexpr int64_t FORCE_MAXGAP_ = 10;  // FORCE_MAXGAP_LEN, banded_smith_waterman.hpp:37
+
+struct Ctx;
+
+struct DevSeq {
+    u32* p2;  // word holding base 0 in the 2-bit plane
+    u32* pn;  // word holding base 0 in the N plane
+};
+
+// RefSequence equivalent: host codes (1 B/base, for findHits and lazy reverse complements) plus the
+// packed planes resident in HBM.
+struct SeqSet {
+    Ctx* ctx = nullptr;
+    std::vector<std::vector<uint8_t>> codes;
+    std::vector<uint8_t> has_n;
+    std::vector<DevSeq> fwd;
+    mutable std::vector<DevSeq> rc;  // reverse complements, uploaded on first use
+    mutable std::vector<u32*> rc_allocs;
+    u32 *d2 = nullptr, *dn = nullptr;
+
+    int upload(Ctx* ctx, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, bool ascii);
+    int ensure_rc(const std::vector<u32>& ids) const;
+    ~SeqSet();
+};
+
+// one find_alignment call with explicit sequence sets per operand (the tails of findBestAlignment
+// put the slave contig in the `a` role, PctgBuilder.cc:1544-1551)
+struct ITask {
+    const SeqSet* sa;
+    const SeqSet* sb;
+    u32 a_id, b_id;
+    u64 a_off, b_off;
+    bool a_rc, b_rc, force_start, force_end;
+    u32 band;
+    u64 begin_a, end_a, begin_b, end_b;
+};
+
+struct Ctx {
+    int device = -1;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    u64 arena_limit = 0;
+
+    u32* d_scratch = nullptr; u64 cap_scratch = 0;  // in u32 words
+    DevTask* d_tasks = nullptr; u64 cap_tasks = 0;
+    DevResult* d_results = nullptr; u64 cap_results = 0;
+    uint8_t* d_ops = nullptr; u64 cap_ops = 0;
+    u32* d_cursor = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double kernel_ms = 0;
+    u64 kernel_launches = 0;
+
+    void set_error(const std::string& s) { err = s; }
+    int init(int dev);
+    int align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops);
+    ~Ctx();
+};
+
+// ABlast::findHits (ablast.cc:41-76) on code arrays
+void find_hits(const uint8_t* a, u64 alen, u64 a_start, u64 a_end, const uint8_t* b, u64 blen, u64 b_start, u64 b_end,
+               u64 word, std::vector<uint32_t>& hits);
+
+}  // namespace gamdp

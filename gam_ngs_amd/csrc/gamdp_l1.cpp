@@ -1,0 +1,354 @@
+// L1: the merge-block chain driver -- a batched, round-based re-design of
+//   PctgBuilder::alignMergeBlock    lib/src/pctg/PctgBuilder.cc:726-844
+//   PctgBuilder::findBestAlignment  :1361-1614
+//   PctgBuilder::alignBlocks        :1617-1708
+//   PctgBuilder::is_good            :1711-1730
+// and ABlast::findHits (lib/src/alignment/ablast.cc:41-76).
+//
+// The reference walks one merge block at a time and blocks on every find_alignment call.  Inside a
+// merge block the DP calls form a serial chain (block k starts where block k-1's last match ended,
+// then up to one orientation retry and two tail alignments), but different merge blocks are
+// independent (BuildPctgFunctions.cc:82-84).  Here every merge block is a small state machine; each
+// round collects the next pending DP call of every unfinished merge block into ONE gamdp L0 batch on
+// the GPU, feeds the results back and advances the machines.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "gamdp.h"
+#include "gamdp_internal.h"
+
+namespace gamdp {
+
+// ---- ABlast::findHits ---------------------------------------------------------------------------
+void find_hits(const uint8_t* a, u64 alen, u64 a_start, u64 a_end, const uint8_t* b, u64 blen, u64 b_start, u64 b_end,
+               u64 word, std::vector<uint32_t>& hits)
+{
+    hits.clear();
+    if (alen == 0 || blen == 0) return;                                   // ablast.cc:47
+    if (a_end >= alen) a_end = alen - 1;                                  // :49-50
+    if (b_end >= blen) b_end = blen - 1;
+    if (a_start > a_end || b_start > b_end) return;                       // :52
+    if (a_end + 1 < word + a_start || b_end + 1 < word + b_start) return; // :53
+    if (word == 0) return;
+
+    // k-mer codes are base-4 numbers with digits 0..4 (ablast.hpp:53-59), rolled along the window
+    u64 top = 1;  // 4^(word-1) mod 2^64
+    for (u64 i = 1; i < word; i++) top *= 4;
+    auto roll = [&](const uint8_t* s, u64 first, u64 last, auto&& emit) {
+        u64 code = 0;
+        for (u64 i = first; i < first + word; i++) code = 4 * code + s[i];
+        for (u64 p = first;; p++) {
+            emit(code, p);
+            if (p == last) break;
+            code = 4 * (code - top * s[p]) + s[p + word];
+        }
+    };
+    std::vector<std::pair<u64, u32>> idx;
+    idx.reserve(a_end - word + 2 - a_start);
+    roll(a, a_start, a_end - word + 1, [&](u64 code, u64 p) { idx.push_back({code, (u32)p}); });
+    std::sort(idx.begin(), idx.end());  // per code: positions ascending, like the reference's lists
+
+    std::vector<u64> f(a_end - a_start + 1, 0);
+    roll(b, b_start, b_end - word + 1, [&](u64 code, u64 bp) {
+        auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(code, (u32)0));
+        const u64 ib = bp - b_start;
+        for (; it != idx.end() && it->first == code; ++it) {
+            const u64 ia = it->second - a_start;
+            if (ia >= ib) f[ia - ib]++;  // mark_found, ablast.hpp:71-78
+        }
+    });
+    u64 best = 0;
+    for (u64 v : f) best = std::max(best, v);
+    if (best == 0) return;
+    for (u64 i = 0; i < f.size(); i++)
+        if (f[i] == best) hits.push_back((uint32_t)(a_start + i));
+}
+
+// ---- merge-block state machine ------------------------------------------------------------------
+namespace {
+
+constexpr double MIN_HOMOLOGY = 95.0;  // PctgBuilder.hpp:63
+
+inline int32_t frame_len(int32_t b, int32_t e) { return e < b ? 0 : e - b + 1; }  // Frame.cc:124-127
+inline u64 umin(u64 x, u64 y) { return x < y ? x : y; }
+
+struct Machine {
+    enum Phase { MAIN, LEFT, RIGHT, DONE };
+    const gamdp_mb_in* in = nullptr;
+    gamdp_mb_out* out = nullptr;
+    const SeqSet *ms = nullptr, *ss = nullptr;
+    u64 mlen = 0, slen = 0;
+    u32 band = GAMDP_DEFAULT_BAND;
+    Phase phase = DONE;
+    // region (alignMergeBlock :741-744) and orientation evidence (findBestAlignment :1380-1408)
+    u64 m_start = 0, s_start = 0, s_end = 0;
+    double con_prob = 0;
+    u64 mt = 0, st = 0, align_thr = 0, thr = 0;
+    bool forward = true;
+    // main chain
+    int attempt = 0;
+    bool try_rev = false;
+    u32 k = 0;
+    int64_t cur_ms = 0, cur_ss = 0;
+    u64 last_a = 0, last_b = 0;
+    std::vector<gamdp_result> A;
+    bool rev = false;
+    // tails
+    u64 sa = 0, sb = 0, ea = 0, eb = 0, i1 = 0, i2 = 0, j1 = 0, j2 = 0;
+    gamdp_result left{}, right{};
+    bool left_rev = false, right_rev = false;  // the reference leaves these uninitialised when a tail is skipped
+    // audit
+    gamdp_result* audit = nullptr;
+    u32 audit_cap = 0;
+
+    const gamdp_block& blk(u32 i) const { return forward ? in->blocks[i] : in->blocks[in->n_blocks - 1 - i]; }
+
+    void finish_bad(int status)
+    {
+        out->status = (uint8_t)status;
+        out->align_ok = 0;
+        phase = DONE;
+    }
+
+    void init()
+    {
+        out->align_ok = 1;  // :757
+        out->align_rev = 0; out->status = GAMDP_ST_OK; out->coords_set = 0;
+        out->m_start = out->m_end = out->s_start = out->s_end = 0;
+        out->n_dp = 0; out->cells = 0;
+        const u32 n = in->n_blocks;
+        if (n == 0 || !in->blocks) { finish_bad(GAMDP_ST_INVALID); return; }  // front() of an empty list: UB
+        const gamdp_block &fb = in->blocks[0], &lb = in->blocks[n - 1];
+        m_start = (u64)(int64_t)std::min(fb.m_begin, lb.m_begin);
+        s_start = (u64)(int64_t)std::min(fb.s_begin, lb.s_begin);
+        s_end = (u64)(int64_t)std::max(fb.s_end, lb.s_end);
+        forward = fb.m_begin <= lb.m_begin;  // :1650
+        u64 con = 0, dis = 0;
+        int32_t min_frame_len = 100;
+        for (u32 i = 0; i < n; i++) {
+            const gamdp_block& b = in->blocks[i];
+            const int32_t mn = std::min(frame_len(b.m_begin, b.m_end), frame_len(b.s_begin, b.s_end));
+            if (i == 0 || min_frame_len > mn) min_frame_len = mn;
+            if (b.m_strand != b.s_strand) dis += (u64)b.n_reads; else con += (u64)b.n_reads;
+        }
+        con_prob = (double)con / (double)(con + dis);
+        mt = (u64)(0.3 * (double)mlen);
+        st = (u64)(0.3 * (double)slen);
+        align_thr = (u64)(int64_t)(int32_t)(0.7 * min_frame_len);
+        thr = (u64)(int64_t)(int32_t)umin(200, umin(mt, st));
+        A.assign(n, gamdp_result{});
+        attempt = 0;
+        if (con_prob >= 0.5) try_rev = false;
+        else if (con_prob < 0.5) try_rev = true;
+        else { finish_bad(GAMDP_ST_OK); return; }  // NaN: neither branch of :1420/:1463 runs
+        start_attempt();
+    }
+
+    void start_attempt()
+    {
+        phase = MAIN;
+        k = 0;
+        cur_ms = (int64_t)m_start;
+        // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
+        cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);
+        last_a = last_b = 0;
+    }
+
+    // the next find_alignment call of this merge block
+    void pending(ITask& t, std::unordered_map<u32, std::vector<uint8_t>>& rc_cache)
+    {
+        t = ITask{};
+        t.band = band;
+        if (phase == MAIN) {
+            const gamdp_block& cur = blk(k);
+            const int32_t ml = frame_len(cur.m_begin, cur.m_end), sl = frame_len(cur.s_begin, cur.s_end);
+            if (k > 0) {  // :1660-1667
+                const gamdp_block& prev = blk(k - 1);
+                const int32_t mgap = prev.m_begin <= cur.m_begin ? (cur.m_begin - prev.m_end - 1) : (prev.m_begin - cur.m_end - 1);
+                const int32_t sgap = prev.s_begin <= cur.s_begin ? (cur.s_begin - prev.s_end - 1) : (prev.s_begin - cur.s_end - 1);
+                cur_ms = (int64_t)(last_a + (u64)(int64_t)mgap); if (cur_ms < 0) cur_ms = 0;
+                cur_ss = (int64_t)(last_b + (u64)(int64_t)sgap); if (cur_ss < 0) cur_ss = 0;
+            }
+            t.sa = ms; t.a_id = (u32)in->m_id; t.sb = ss; t.b_id = (u32)in->s_id; t.b_rc = try_rev;
+            t.begin_a = (u64)cur_ms; t.end_a = (u64)(cur_ms + ml - 1);
+            t.begin_b = (u64)cur_ss; t.end_b = (u64)(cur_ss + sl - 1);
+            return;
+        }
+        const uint8_t* mc = ms->codes[in->m_id].data();
+        const uint8_t* sc;
+        if (rev) {
+            auto it = rc_cache.find((u32)in->s_id);
+            if (it == rc_cache.end()) {
+                std::vector<uint8_t> r = ss->codes[in->s_id];
+                gamdp_revcomp(r.data(), r.size());
+                it = rc_cache.emplace((u32)in->s_id, std::move(r)).first;
+            }
+            sc = it->second.data();
+        } else sc = ss->codes[in->s_id].data();
+        std::vector<uint32_t> hits;
+        if (phase == LEFT) {  // :1535-1569, force_end
+            t.force_end = true;
+            if (i1 < j1) {
+                find_hits(sc, slen, 0, sb - 1, mc, mlen, 0, sa - 1, 20, hits);
+                t.sa = ss; t.a_id = (u32)in->s_id; t.a_rc = rev; t.sb = ms; t.b_id = (u32)in->m_id;
+                t.begin_a = hits.empty() ? sb - sa : hits.back(); t.end_a = sb - 1; t.begin_b = 0; t.end_b = sa - 1;
+                left_rev = true;
+            } else {
+                find_hits(mc, mlen, 0, sa - 1, sc, slen, 0, sb - 1, 20, hits);
+                t.sa = ms; t.a_id = (u32)in->m_id; t.sb = ss; t.b_id = (u32)in->s_id; t.b_rc = rev;
+                t.begin_a = hits.empty() ? sa - sb : hits.back(); t.end_a = sa - 1; t.begin_b = 0; t.end_b = sb - 1;
+                left_rev = false;
+            }
+        } else {  // RIGHT :1573-1611, force_start; the chop_begin copy becomes a suffix view
+            t.force_start = true;
+            if (i2 < j2) {
+                const u64 tl = slen - (eb + 1);
+                find_hits(sc + eb + 1, tl, 0, tl - 1, mc, mlen, ea + 1, mlen - 1, 20, hits);
+                t.sa = ss; t.a_id = (u32)in->s_id; t.a_rc = rev; t.a_off = eb + 1; t.sb = ms; t.b_id = (u32)in->m_id;
+                t.begin_a = hits.empty() ? 0 : hits.front(); t.end_a = tl - 1; t.begin_b = ea + 1; t.end_b = mlen - 1;
+                right_rev = true;
+            } else {
+                const u64 tl = mlen - (ea + 1);
+                find_hits(mc + ea + 1, tl, 0, tl - 1, sc, slen, eb + 1, slen - 1, 20, hits);
+                t.sa = ms; t.a_id = (u32)in->m_id; t.a_off = ea + 1; t.sb = ss; t.b_id = (u32)in->s_id; t.b_rc = rev;
+                t.begin_a = hits.empty() ? 0 : hits.front(); t.end_a = tl - 1; t.begin_b = eb + 1; t.end_b = slen - 1;
+                right_rev = false;
+            }
+        }
+    }
+
+    bool good_vec() const
+    {  // is_good(vector), :1711-1724
+        u64 len = 0;
+        for (const gamdp_result& r : A) { if (r.homology < MIN_HOMOLOGY) return false; len += r.length; }
+        return len >= align_thr;
+    }
+    static bool good_one(const gamdp_result& r, u64 min_len) { return r.homology >= MIN_HOMOLOGY && r.length >= min_len; }
+
+    void enter_right_or_finalize()
+    {
+        if (umin(i2, j2) >= thr) {
+            // chop_borders throws std::domain_error when nothing is left to keep (contig.code.hpp:236-238)
+            if ((i2 < j2 && slen <= eb + 1) || (!(i2 < j2) && mlen <= ea + 1)) { finish_bad(GAMDP_ST_OUT_OF_RANGE); return; }
+            phase = RIGHT;
+        } else finalize();
+    }
+
+    void after_main_good()
+    {
+        sa = A.front().first_a; sb = A.front().first_b;     // :1515-1517
+        ea = A.back().last_a; eb = A.back().last_b;
+        i1 = sa; i2 = mlen - ea - 1; j1 = sb; j2 = slen - eb - 1;
+        std::memset(&left, 0, sizeof(left)); std::memset(&right, 0, sizeof(right));
+        left.homology = right.homology = 100.0;             // MyAlignment(100)
+        left_rev = right_rev = false;
+        if (umin(i1, j1) < thr && umin(i2, j2) < thr) { finalize(); return; }  // :1526
+        if (umin(i1, j1) >= thr) phase = LEFT;
+        else enter_right_or_finalize();
+    }
+
+    void feed(const gamdp_result& r)
+    {
+        if (audit && out->n_dp < audit_cap) audit[out->n_dp] = r;
+        out->n_dp++;
+        out->cells += r.cells;
+        if (r.status == GAMDP_ST_OUT_OF_RANGE || r.status == GAMDP_ST_INVALID) { finish_bad(r.status); return; }
+        if (phase == MAIN) {
+            A[k] = r;
+            last_a = r.last_a; last_b = r.last_b;  // last_match_pos; (0,0) for an empty alignment
+            if (++k < in->n_blocks) return;
+            if (good_vec()) { rev = try_rev; after_main_good(); return; }
+            if (++attempt == 2) { finish_bad(GAMDP_ST_OK); return; }  // :1512 -> :825-829, coords untouched
+            try_rev = !try_rev;
+            start_attempt();
+        } else if (phase == LEFT) {
+            left = r;
+            enter_right_or_finalize();
+        } else if (phase == RIGHT) {
+            right = r;
+            finalize();
+        }
+    }
+
+    void finalize()
+    {  // alignMergeBlock :759-843 (main_homology() >= 95 is implied by good_vec())
+        const u64 thr2 = umin(100, umin(mt, st));
+        const u64 left_min = (u64)(0.7 * (double)umin(i1, j1));
+        const u64 right_min = (u64)(0.7 * (double)umin(i2, j2));
+        const bool s_lt = rev ? in->s_rtail : in->s_ltail;
+        const bool s_rt = rev ? in->s_ltail : in->s_rtail;
+        u64 Sa = sa, Sb = sb, Ea = ea, Eb = eb;
+        if (in->m_ltail && s_lt && umin(i1, j1) >= thr2) {
+            if (good_one(left, left_min)) {
+                Sa = left.first_a; Sb = left.first_b;
+                if (left_rev) std::swap(Sa, Sb);
+            } else out->align_ok = 0;
+        }
+        if (in->m_rtail && s_rt && umin(i2, j2) >= thr2) {
+            if (good_one(right, right_min)) {
+                u64 ta = right.last_a, tb = right.last_b;
+                if (right_rev) { std::swap(ta, tb); Ea = ta; Eb += tb + 1; }
+                else { Ea += ta + 1; Eb = tb; }
+            } else out->align_ok = 0;
+        }
+        if (rev) { const u64 t = Sb; Sb = slen - Eb - 1; Eb = slen - t - 1; }  // :831-836
+        out->align_rev = rev;
+        out->m_start = (int32_t)Sa; out->m_end = (int32_t)Ea;
+        out->s_start = (int32_t)Sb; out->s_end = (int32_t)Eb;
+        out->coords_set = 1;
+        phase = DONE;
+    }
+};
+
+}  // namespace
+}  // namespace gamdp
+
+using namespace gamdp;
+
+extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* master, const gamdp_seqset* slave,
+                                        const gamdp_mb_in* in, size_t n, uint32_t band, gamdp_mb_out* out,
+                                        gamdp_result* audit, uint32_t audit_stride)
+{
+    if (!ctx || !master || !slave || (n && (!in || !out))) return GAMDP_EINVAL;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    const SeqSet* ms = reinterpret_cast<const SeqSet*>(master);
+    const SeqSet* ss = reinterpret_cast<const SeqSet*>(slave);
+    if (band > GAMDP_MAX_BAND) { c->set_error("band exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
+    std::vector<Machine> M(n);
+    for (size_t i = 0; i < n; i++) {
+        Machine& m = M[i];
+        m.in = &in[i]; m.out = &out[i]; m.ms = ms; m.ss = ss; m.band = band;
+        if (in[i].m_id < 0 || in[i].s_id < 0 || (size_t)in[i].m_id >= ms->codes.size() || (size_t)in[i].s_id >= ss->codes.size()) {
+            c->set_error("merge block " + std::to_string(i) + ": contig id out of range");
+            return GAMDP_EINVAL;
+        }
+        m.mlen = ms->codes[in[i].m_id].size();
+        m.slen = ss->codes[in[i].s_id].size();
+        if (audit) { m.audit = audit + i * (size_t)audit_stride; m.audit_cap = audit_stride; }
+        m.init();
+    }
+    std::unordered_map<u32, std::vector<uint8_t>> rc_cache;
+    std::vector<ITask> tasks;
+    std::vector<size_t> owner;
+    std::vector<gamdp_result> res;
+    for (;;) {
+        tasks.clear();
+        owner.clear();
+        for (size_t i = 0; i < n; i++) {
+            if (M[i].phase == Machine::DONE) continue;
+            ITask t;
+            M[i].pending(t, rc_cache);
+            tasks.push_back(t);
+            owner.push_back(i);
+        }
+        if (tasks.empty()) break;
+        res.assign(tasks.size(), gamdp_result{});
+        const int rc_ = c->align(tasks, res.data(), nullptr);
+        if (rc_) return rc_;
+        for (size_t q = 0; q < tasks.size(); q++) M[owner[q]].feed(res[q]);
+    }
+    return 0;
+}

@@ -1,0 +1,112 @@
+"""ctypes binding of libgamdp.so: one Python declaration per symbol of include/gamdp.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every function include/gamdp.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "gamdp_ctx_create", "gamdp_ctx_destroy", "gamdp_ctx_set_arena_bytes", "gamdp_last_error", "gamdp_ctx_stream",
+    "gamdp_ctx_kernel_time", "gamdp_seqset_create", "gamdp_seqset_destroy", "gamdp_seqset_size",
+    "gamdp_seqset_length", "gamdp_align_batch", "gamdp_align_merge_blocks", "gamdp_find_hits", "gamdp_encode",
+    "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair",
+]
+
+EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
+ST_OK, ST_EMPTY, ST_OUT_OF_RANGE, ST_INVALID = 0, 1, 2, 3
+
+
+class GamdpError(RuntimeError):
+    pass
+
+
+class Task(C.Structure):
+    _fields_ = [("a_id", C.c_uint32), ("b_id", C.c_uint32), ("a_off", C.c_uint64), ("b_off", C.c_uint64),
+                ("a_rc", C.c_uint8), ("b_rc", C.c_uint8), ("force_start", C.c_uint8), ("force_end", C.c_uint8),
+                ("band", C.c_uint32), ("begin_a", C.c_uint64), ("end_a", C.c_uint64), ("begin_b", C.c_uint64),
+                ("end_b", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("begin_a", C.c_uint64), ("begin_b", C.c_uint64), ("score", C.c_int64), ("n_match", C.c_uint64),
+                ("length", C.c_uint64), ("first_a", C.c_uint64), ("first_b", C.c_uint64), ("last_a", C.c_uint64),
+                ("last_b", C.c_uint64), ("cells", C.c_uint64), ("homology", C.c_double),
+                ("first_found", C.c_uint8), ("last_found", C.c_uint8), ("status", C.c_uint8), ("pad_", C.c_uint8 * 5)]
+
+    def key(self):
+        """Same tuple layout as the oracle's / golden vectors' keys."""
+        return (self.status, self.begin_a, self.begin_b, self.score, self.n_match, self.length, self.first_a,
+                self.first_b, self.first_found, self.last_a, self.last_b, self.last_found, self.homology)
+
+
+class Ops(C.Structure):
+    _fields_ = [("ops_buf", C.c_void_p), ("ops_off", C.POINTER(C.c_uint64)), ("ops_cap", C.POINTER(C.c_uint64))]
+
+
+class BlockC(C.Structure):
+    _fields_ = [("m_begin", C.c_int32), ("m_end", C.c_int32), ("s_begin", C.c_int32), ("s_end", C.c_int32),
+                ("m_strand", C.c_char), ("s_strand", C.c_char), ("n_reads", C.c_int64)]
+
+
+class MbIn(C.Structure):
+    _fields_ = [("m_id", C.c_int32), ("s_id", C.c_int32), ("m_ltail", C.c_uint8), ("m_rtail", C.c_uint8),
+                ("s_ltail", C.c_uint8), ("s_rtail", C.c_uint8), ("n_blocks", C.c_uint32),
+                ("blocks", C.POINTER(BlockC))]
+
+
+class MbOut(C.Structure):
+    _fields_ = [("align_ok", C.c_uint8), ("align_rev", C.c_uint8), ("status", C.c_uint8), ("coords_set", C.c_uint8),
+                ("m_start", C.c_int32), ("m_end", C.c_int32), ("s_start", C.c_int32), ("s_end", C.c_int32),
+                ("n_dp", C.c_uint32), ("cells", C.c_uint64)]
+
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(HERE, "libgamdp.so")
+
+
+def load_library():
+    """Loads libgamdp.so (raises GamdpError if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GamdpError("%s is missing: build it with `make -C gam_ngs_amd/csrc` "
+                         "(or __graft_entry__.build()); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    u64, u32, vp = C.c_uint64, C.c_uint32, C.c_void_p
+    lib.gamdp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.gamdp_ctx_create.restype = C.c_int
+    lib.gamdp_ctx_destroy.argtypes = [vp]
+    lib.gamdp_ctx_destroy.restype = None
+    lib.gamdp_ctx_set_arena_bytes.argtypes = [vp, u64]
+    lib.gamdp_last_error.argtypes = [vp]
+    lib.gamdp_last_error.restype = C.c_char_p
+    lib.gamdp_ctx_stream.argtypes = [vp]
+    lib.gamdp_ctx_stream.restype = vp
+    lib.gamdp_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.c_int]
+    lib.gamdp_seqset_create.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(vp)]
+    lib.gamdp_seqset_destroy.argtypes = [vp]
+    lib.gamdp_seqset_destroy.restype = None
+    lib.gamdp_seqset_size.argtypes = [vp]
+    lib.gamdp_seqset_size.restype = u32
+    lib.gamdp_seqset_length.argtypes = [vp, u32]
+    lib.gamdp_seqset_length.restype = u64
+    lib.gamdp_align_batch.argtypes = [vp, vp, vp, C.POINTER(Task), C.c_size_t, C.POINTER(Result), C.POINTER(Ops)]
+    lib.gamdp_align_merge_blocks.argtypes = [vp, vp, vp, C.POINTER(MbIn), C.c_size_t, u32, C.POINTER(MbOut),
+                                             C.POINTER(Result), u32]
+    lib.gamdp_find_hits.argtypes = [C.c_char_p, u64, u64, u64, C.c_char_p, u64, u64, u64, u64, vp, u64]
+    lib.gamdp_find_hits.restype = C.c_int64
+    lib.gamdp_encode.argtypes = [C.c_char_p, u64, vp]
+    lib.gamdp_encode.restype = None
+    lib.gamdp_decode.argtypes = [vp, u64, vp]
+    lib.gamdp_decode.restype = None
+    lib.gamdp_revcomp.argtypes = [vp, u64]
+    lib.gamdp_revcomp.restype = None
+    lib.gamdp_synth_pair.argtypes = [u64, u64, vp, vp]
+    lib.gamdp_synth_pair.restype = u64
+    _lib = lib
+    return lib

@@ -1,0 +1,177 @@
+/* gamdp.h -- C ABI of libgamdp: MI355X (gfx950) implementation of gam-merge's contig-pair
+ * alignment hot path.  Plain C types only; no C++/torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *
+ *   gamdp_align_batch          N independent calls of
+ *                              BandedSmithWaterman(band).find_alignment(a,begin_a,end_a,b,begin_b,end_b,
+ *                              force_start,force_end)        lib/include/alignment/banded_smith_waterman.hpp:66-71
+ *                              (lib/src/alignment/banded_smith_waterman.cc:69-322) plus the
+ *                              first_match_pos / last_match_pos scans of each result
+ *                              (lib/src/alignment/my_alignment.cc:167-193, 228-262).
+ *   gamdp_find_hits            ABlast(word).findHits(...)    lib/src/alignment/ablast.cc:41-76
+ *   gamdp_align_merge_blocks   the loop `for list: for mb: builder.alignMergeBlock(graph,*mb)`
+ *                              lib/src/pctg/BuildPctgFunctions.cc:82-84, i.e. N calls of
+ *                              PctgBuilder::alignMergeBlock  lib/src/pctg/PctgBuilder.cc:726-844
+ *                              (findBestAlignment :1361-1614, alignBlocks :1617-1708, is_good :1711-1730).
+ *   gamdp_seqset_*             the RefSequence vectors filled by loadSequences
+ *                              (lib/include/assembly/io_contig.code.hpp:568-596) -- uploaded once per GPU.
+ *   gamdp_encode / _revcomp    Nucleotide(char) (lib/include/assembly/nucleotide.code.hpp:47-75) and
+ *                              reverse_complement (lib/include/assembly/contig.code.hpp:187-229).
+ *
+ * Conventions: every function returns 0 on success or a negative GAMDP_E* code; nothing throws;
+ * the caller owns every buffer it passes; a gamdp_ctx binds one GPU + one HIP stream and must be
+ * used by one host thread at a time (one ctx per thread / per GPU).  There is NO CPU fallback:
+ * with no usable gfx950 device gamdp_ctx_create fails with GAMDP_ENODEV.
+ */
+#ifndef GAMDP_H
+#define GAMDP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAMDP_VERSION 1
+
+/* error codes (negative return values) */
+#define GAMDP_EINVAL  (-1)  /* bad argument                                        */
+#define GAMDP_ENODEV  (-2)  /* no usable GPU / HIP runtime failure at context setup */
+#define GAMDP_ENOMEM  (-3)  /* host or device allocation failed                    */
+#define GAMDP_ENOTSUP (-4)  /* band wider than the compiled kernels support        */
+#define GAMDP_EHIP    (-5)  /* a HIP call failed at run time (see gamdp_last_error) */
+
+/* per-task status, mirrors the reference's observable outcomes */
+#define GAMDP_ST_OK           0 /* a MyAlignment was produced                                          */
+#define GAMDP_ST_EMPTY        1 /* reference returns MyAlignment() (banded_smith_waterman.cc:90, :215) */
+#define GAMDP_ST_OUT_OF_RANGE 2 /* reference throws std::out_of_range from Contig::at; gam-merge then
+                                   drops the whole graph (lib/src/pctg/ThreadedBuildPctg.cc:322-329)   */
+#define GAMDP_ST_INVALID      3 /* arguments for which the reference has undefined behaviour           */
+
+/* edit-string alphabet (lib/include/alignment/my_alignment.hpp:57-62) */
+#define GAMDP_OP_GAP_A 0
+#define GAMDP_OP_GAP_B 1
+#define GAMDP_OP_MATCH 2
+#define GAMDP_OP_MISMATCH 3
+
+#define GAMDP_DEFAULT_BAND 150   /* DEFAULT_BAND_SIZE, banded_smith_waterman.hpp:38 */
+#define GAMDP_MAX_BAND 543       /* widest band the compiled kernels cover (2*band+1 <= 64*17) */
+
+typedef struct gamdp_ctx gamdp_ctx;
+typedef struct gamdp_seqset gamdp_seqset;
+
+/* One find_alignment call.  Sequences are referenced by index into a seqset; *_rc selects the
+ * reverse complement of that sequence (the reference reverse-complements the slave contig in
+ * place, PctgBuilder.cc:1443, 1467); *_off makes the sequence a suffix view seq[off..] (the
+ * reference's chop_begin copy, PctgBuilder.cc:1577, 1596).  Coordinates are relative to the view. */
+typedef struct gamdp_task {
+    uint32_t a_id, b_id;
+    uint64_t a_off, b_off;
+    uint8_t a_rc, b_rc, force_start, force_end;
+    uint32_t band;
+    uint64_t begin_a, end_a, begin_b, end_b;
+} gamdp_task;
+
+/* What the callers of find_alignment consume (PctgBuilder.cc:761-762, 787, 801, 1516-1517, 1672).
+ * homology is (double)(n_match*100)/(double)length, or 0 when length==0, exactly as
+ * banded_smith_waterman.cc:319; it is filled in on the host. */
+typedef struct gamdp_result {
+    uint64_t begin_a, begin_b;   /* MyAlignment::begin_a / begin_b                          */
+    int64_t score;               /* MyAlignment::score                                      */
+    uint64_t n_match, length;    /* #MATCH ops, #ops                                        */
+    uint64_t first_a, first_b;   /* first_match_pos                                         */
+    uint64_t last_a, last_b;     /* last_match_pos                                          */
+    uint64_t cells;              /* x_size*y_size of the reference's fill loops (GCUPS unit) */
+    double homology;
+    uint8_t first_found, last_found; /* bool results of first/last_match_pos               */
+    uint8_t status;              /* GAMDP_ST_*                                              */
+    uint8_t pad_[5];
+} gamdp_result;
+
+/* Optional edit strings: ops[task i] occupies ops_buf[ops_off[i] .. ops_off[i]+length) in forward
+ * order, truncated to ops_cap[i].  The caller fills ops_off/ops_cap; pass NULL to skip. */
+typedef struct gamdp_ops {
+    uint8_t* ops_buf;
+    const uint64_t* ops_off;
+    const uint64_t* ops_cap;
+} gamdp_ops;
+
+/* Block / Frame fields the merge-block driver reads (Frame::getBegin/getEnd/getStrand,
+ * Block::getReadsNumber; lib/src/assembly/Frame.cc:100-127, Block.cc:79-82). */
+typedef struct gamdp_block {
+    int32_t m_begin, m_end, s_begin, s_end;
+    char m_strand, s_strand;
+    int64_t n_reads;
+} gamdp_block;
+
+/* MergeBlock (lib/include/pctg/MergeDescriptor.hpp:40-69): inputs the driver reads ... */
+typedef struct gamdp_mb_in {
+    int32_t m_id, s_id;                       /* indices into the master / slave seqsets */
+    uint8_t m_ltail, m_rtail, s_ltail, s_rtail;
+    uint32_t n_blocks;
+    const gamdp_block* blocks;                /* graph.getBlocks(mb.vertex), in list order */
+} gamdp_mb_in;
+
+/* ... and the fields it writes. coords_set==0 means the reference returned before writing
+ * align_rev/m_start/... (PctgBuilder.cc:825-829) so the caller must leave them untouched. */
+typedef struct gamdp_mb_out {
+    uint8_t align_ok, align_rev;
+    uint8_t status;       /* GAMDP_ST_OK, or OUT_OF_RANGE/INVALID: the reference would throw -> drop graph */
+    uint8_t coords_set;
+    int32_t m_start, m_end, s_start, s_end;
+    uint32_t n_dp;        /* find_alignment calls made for this merge block */
+    uint64_t cells;       /* sum of their cells                              */
+} gamdp_mb_out;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int gamdp_ctx_create(int device, gamdp_ctx** out);
+void gamdp_ctx_destroy(gamdp_ctx* ctx);
+/* bound the scratch arena (direction matrix) in bytes; 0 = default (60 % of free HBM) */
+int gamdp_ctx_set_arena_bytes(gamdp_ctx* ctx, uint64_t bytes);
+const char* gamdp_last_error(const gamdp_ctx* ctx);
+/* the hipStream_t the kernels run on, as an opaque pointer */
+void* gamdp_ctx_stream(gamdp_ctx* ctx);
+/* HIP-event timing of the DP kernel launches since the last reset: total ms and launch count */
+int gamdp_ctx_kernel_time(gamdp_ctx* ctx, double* total_ms, uint64_t* launches, int reset);
+
+/* ---- sequences ---------------------------------------------------------------------------- */
+/* seqs[i] points to lens[i] bytes: ASCII bases when is_ascii!=0 (normalised like Nucleotide(char)),
+ * else base codes A=0 T=1 C=2 G=3 N=4.  Packs to 2 bit + N mask and uploads to the ctx's GPU. */
+int gamdp_seqset_create(gamdp_ctx* ctx, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n,
+                        int is_ascii, gamdp_seqset** out);
+void gamdp_seqset_destroy(gamdp_seqset* set);
+uint32_t gamdp_seqset_size(const gamdp_seqset* set);
+uint64_t gamdp_seqset_length(const gamdp_seqset* set, uint32_t id);
+
+/* ---- L0: batch of independent banded alignments ------------------------------------------- */
+/* a sequences come from set_a, b sequences from set_b (may be the same set). */
+int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seqset* set_b,
+                      const gamdp_task* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops_or_null);
+
+/* ---- L1: batch of merge blocks ------------------------------------------------------------ */
+/* band is DEFAULT_BAND_SIZE (150) in the reference.  audit (optional) receives, per merge block i,
+ * up to audit_stride results of its DP calls in call order at audit[i*audit_stride ...]. */
+int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* master, const gamdp_seqset* slave,
+                             const gamdp_mb_in* in, size_t n, uint32_t band, gamdp_mb_out* out,
+                             gamdp_result* audit, uint32_t audit_stride);
+
+/* ---- host-side helpers on the path -------------------------------------------------------- */
+/* ABlast::findHits on code arrays; returns the number of hits (first cap written) or <0. */
+int64_t gamdp_find_hits(const uint8_t* a, uint64_t alen, uint64_t a_start, uint64_t a_end,
+                        const uint8_t* b, uint64_t blen, uint64_t b_start, uint64_t b_end,
+                        uint64_t word, uint32_t* hits, uint64_t cap);
+void gamdp_encode(const char* chars, uint64_t n, uint8_t* codes);
+void gamdp_decode(const uint8_t* codes, uint64_t n, char* chars);
+void gamdp_revcomp(uint8_t* codes, uint64_t n);
+
+/* Synthetic pair k of the benchmark workload (BASELINE.json config 5): master = len uniform ACGT
+ * codes, slave = master with 3 % substitutions, 1 % insertions, 1 % deletions (splitmix64 keyed by
+ * k).  slave must hold len + len/8 + 64 codes; returns the slave length. */
+uint64_t gamdp_synth_pair(uint64_t k, uint64_t len, uint8_t* master, uint8_t* slave);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAMDP_H */

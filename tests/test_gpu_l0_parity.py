@@ -1,0 +1,140 @@
+"""GPU parity of gamdp_align_batch (HIP kernels, through the C ABI) against the reference-generated
+golden vectors and the CPU oracle: bit-exact on every field a caller of find_alignment can observe
+(begin_a/b, score, #matches, length, homology, first/last match, status) and on the edit string."""
+import ctypes
+import random
+import zlib
+
+import pytest
+
+import _cases
+import _golden as G
+import _oracle as O
+from _gpu import ctx, oracle_for, run_cases
+import gam_ngs_amd as gam
+from gam_ngs_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_small_cases_with_ops():
+    items = G.l0_cases()
+    res = run_cases([c for _, c, _ in items], want_ops=True)
+    bad = []
+    for (name, c, e), r in zip(items, res):
+        if r.key() != G.expect_key(e) or (e.get("ops") is not None and r.ops != e["ops"]):
+            bad.append((name, r.key(), G.expect_key(e)))
+    assert not bad, bad[:5]
+    assert len(items) >= 650
+
+
+def test_golden_small_cases_summary_only_path():
+    # without ops the kernel takes the run-skipping traceback: same summaries required
+    items = G.l0_cases()
+    res = run_cases([c for _, c, _ in items], want_ops=False)
+    bad = [(name, r.key(), G.expect_key(e)) for (name, c, e), r in zip(items, res) if r.key() != G.expect_key(e)]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cases_vs_oracle(seed):
+    bands = [(0, 1, 2, 5, 8, 20, 150), (3, 31, 32, 63, 64, 95, 96), (150, 151, 160, 161, 287, 288), (512, 300, 543, 20)][seed % 4]
+    cases = _cases.cases(9000 + seed, 500, max_len=400 if seed < 4 else 1500, bands=bands)
+    for want_ops in (True, False):
+        res = run_cases(cases, want_ops=want_ops)
+        bad = []
+        n_ok = 0
+        for cs, r in zip(cases, res):
+            o, ops = oracle_for(cs, want_ops)
+            if o.status == O.INVALID:
+                continue
+            if r.key() != o.key() or (want_ops and r.ops != ops):
+                bad.append((cs, r.key(), o.key()))
+            n_ok += o.status == O.OK
+        assert not bad, bad[:3]
+        assert n_ok > 200
+
+
+def test_medium_pairs_all_kernel_variants():
+    rng = random.Random(12)
+    cases = []
+    for n, band, nfrac in ((3000, 150, 0.0), (3000, 150, 0.01), (2500, 512, 0.0), (2500, 512, 0.02), (4000, 20, 0.0),
+                           (3000, 64, 0.0), (2000, 100, 0.01), (3500, 250, 0.0), (1800, 400, 0.005), (6000, 543, 0.0)):
+        a, b = _cases.related_pair(rng, n, n_frac=nfrac)
+        cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1,
+                          fs=False, fe=False))
+        # a windowed variant with tails on both sides
+        cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=200, end_a=len(a) - 300, begin_b=190,
+                          end_b=len(b) - 310, fs=bool(n % 2), fe=bool(band % 2)))
+    for want_ops in (True, False):
+        res = run_cases(cases, want_ops)
+        for cs, r in zip(cases, res):
+            o, ops = oracle_for(cs, want_ops)
+            assert r.key() == o.key(), (cs["band"], len(cs["a"]), r.key(), o.key())
+            if want_ops:
+                assert r.ops == ops
+
+
+def test_golden_large_synthetic_pairs():
+    """50 kb pairs at band 150 / 512 from the benchmark generator; expected values come from the reference."""
+    c = ctx()
+    gold = G.load("l0_large.json")
+    seqs, calls_meta = [], []
+    for d in gold:
+        m, s = api.synth_pair(d["k"], d["len"])
+        assert len(s) == d["slave_len"]
+        assert zlib.crc32(api.decode(m).encode()) == d["a_crc32"]
+        seqs += [m, s]
+    sset = gam.SequenceSet(c, seqs, ascii=False)
+    calls = [(sset.contig(2 * i), 0, d["len"] - 1, sset.contig(2 * i + 1), 0, d["slave_len"] - 1) for i, d in enumerate(gold)]
+    bsw = gam.BandedSmithWaterman(c)
+    for want_ops in (False, True):
+        res = bsw.find_alignments(calls, want_ops=want_ops, bands=[d["band"] for d in gold])
+        for d, r in zip(gold, res):
+            assert r.key() == G.expect_key(d["expect"]), (d["k"], d["band"])
+            assert r.cells == min(d["slave_len"], d["len"] + d["band"]) * (2 * d["band"] + 1)
+            if want_ops:
+                G.check_ops(d["expect"], r.ops)
+
+
+def test_reverse_complement_and_suffix_views():
+    """a_rc / b_rc / *_off must equal aligning explicitly reverse-complemented / chopped copies."""
+    rng = random.Random(31)
+    c = ctx()
+    a, b = _cases.related_pair(rng, 1500, n_frac=0.01)
+    ca, cb = api.encode(a), api.encode(b)
+    sset = gam.SequenceSet(c, [ca, cb, api.reverse_complement(ca), api.reverse_complement(cb), ca[300:], cb[280:]], ascii=False)
+    bsw = gam.BandedSmithWaterman(c, 150)
+    A, B, Arc, Brc, Achop, Bchop = (sset.contig(i) for i in range(6))
+    pairs = [
+        ((sset.contig(0, rc=True), 0, len(ca) - 1, sset.contig(1, rc=True), 0, len(cb) - 1), (Arc, 0, len(ca) - 1, Brc, 0, len(cb) - 1)),
+        ((sset.contig(0, off=300), 0, len(ca) - 301, sset.contig(1, off=280), 0, len(cb) - 281, True, False),
+         (Achop, 0, len(ca) - 301, Bchop, 0, len(cb) - 281, True, False)),
+        ((A, 10, 900, sset.contig(1, rc=True), 5, 800), (A, 10, 900, Brc, 5, 800)),
+    ]
+    for view_call, copy_call in pairs:
+        r1, r2 = bsw.find_alignments([view_call, copy_call], want_ops=True)
+        assert r1.key() == r2.key() and r1.ops == r2.ops
+    # and against the oracle for the rc case
+    o, ops = O.oracle_align(api.reverse_complement(ca), api.reverse_complement(cb), 150, 0, len(ca) - 1, 0, len(cb) - 1)
+    r = bsw.find_alignment(sset.contig(0, rc=True), 0, len(ca) - 1, sset.contig(1, rc=True), 0, len(cb) - 1, want_ops=True)
+    assert r.key() == o.key() and r.ops == ops
+
+
+def test_band_too_wide_is_refused_loudly():
+    c = ctx()
+    sset = gam.SequenceSet(c, [b"ACGT" * 10, b"ACGT" * 10])
+    with pytest.raises(gam.GamdpError):
+        gam.BandedSmithWaterman(c, 600).find_alignment(sset.contig(0), 0, 39, sset.contig(1), 0, 39)
+
+
+def test_empty_batch_and_degenerate_sequences():
+    c = ctx()
+    assert gam.BandedSmithWaterman(c).find_alignments([]) == []
+    cases = [dict(a=b"A", b=b"A", band=150, begin_a=0, end_a=0, begin_b=0, end_b=0, fs=False, fe=False),
+             dict(a=b"A", b=b"C", band=0, begin_a=0, end_a=0, begin_b=0, end_b=0, fs=False, fe=False),
+             dict(a=b"ACGTACGTAC", b=b"A", band=5, begin_a=3, end_a=9, begin_b=0, end_b=5, fs=True, fe=True),
+             dict(a=b"N", b=b"N", band=2, begin_a=0, end_a=3, begin_b=0, end_b=0, fs=False, fe=False)]
+    for cs, r in zip(cases, run_cases(cases)):
+        o, ops = oracle_for(cs)
+        assert r.key() == o.key() and r.ops == ops
