@@ -337,26 +337,40 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             if (prep[x].cells != prep[y].cells) return prep[x].cells > prep[y].cells;
             return x < y;
         });
-        // split the group so that slots sized for its largest task fit the arena
-        size_t pos = 0;
-        while (pos < g.size()) {
+        // One launch per group if slots sized for its largest direction matrix leave enough resident
+        // waves; otherwise peel off the tasks with big matrices into their own launch and retry.
+        std::vector<std::vector<u32>> work;
+        work.push_back(g);
+        while (!work.empty()) {
+            std::vector<u32> cur = std::move(work.back());
+            work.pop_back();
             u32 maxband = 0;
-            for (size_t k = pos; k < g.size(); k++) maxband = std::max<u32>(maxband, (u32)prep[g[k]].dt.band);
+            u64 maxdir = 0;
+            for (u32 i : cur) {
+                maxband = std::max<u32>(maxband, (u32)prep[i].dt.band);
+                maxdir = std::max(maxdir, prep[i].dir_words);
+            }
             const u32 ypad = ((2 * maxband + 2 + 63) / 64) * 64;
-            const u64 dirw = ((prep[g[pos]].dir_words + 63) / 64) * 64;  // largest first
+            const u64 dirw = ((maxdir + 63) / 64) * 64;
             const u64 slotw = dirw + 4ull * ypad;
-            u64 fit = arena_limit / (slotw * sizeof(u32));
+            const u64 fit = arena_limit / (slotw * sizeof(u32));
             if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
-            // tasks much smaller than the head of the list get their own launch (smaller slots, more of them)
-            size_t end = pos;
-            while (end < g.size() && (end - pos < 64 || prep[g[end]].dir_words * 4 >= prep[g[pos]].dir_words)) end++;
+            const u64 want = std::min<u64>(cur.size(), max_resident);
+            if (fit < want && cur.size() > 1) {
+                std::vector<u32> big, small;
+                for (u32 i : cur) (prep[i].dir_words * 2 >= maxdir ? big : small).push_back(i);
+                if (!small.empty()) {
+                    work.push_back(std::move(small));
+                    work.push_back(std::move(big));  // processed first (largest tasks first)
+                    continue;
+                }
+            }
             Launch L;
-            L.kid = kid; L.first = (u32)hostTasks.size(); L.count = (u32)(end - pos);
+            L.kid = kid; L.first = (u32)hostTasks.size(); L.count = (u32)cur.size();
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
-            L.n_slots = (u32)std::min<u64>(std::min<u64>(L.count, max_resident), fit);
-            for (size_t k = pos; k < end; k++) hostTasks.push_back(prep[g[k]].dt);
+            L.n_slots = (u32)std::min<u64>(want, fit);
+            for (u32 i : cur) hostTasks.push_back(prep[i].dt);
             launches.push_back(L);
-            pos = end;
         }
     }
     if (!launches.empty()) {
