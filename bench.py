@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on BASELINE.json's workload: GCUPS of the banded semi-global DP on
+synthetic 50 kb x 50 kb contig pairs (5 % divergence, band 512; generator of SURVEY.md 8d).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
+
+One "step" = one gamdp_align_batch call over this rank's P pairs (fill + end-cell search + traceback
+summary for every pair), sequences already packed and resident in HBM.  For N > 1 the driver starts
+one process per GPU with torch.distributed.run; every rank aligns its own P pairs (the pair list is
+statically partitioned, no data-path collective) -> weak scaling; value = total cells / max-over-ranks time.
+
+The printed JSON line also carries
+  roofline      algorithmic HBM bytes (0.2507 B per cell update) of one kernel launch
+                divided by that launch's HIP-event duration, against the 8 TB/s HBM peak;
+  cpu_baseline  the reference's own find_alignment (oracle/_ref, kind "reference") or, where that build
+                is absent, our C restatement (oracle/, kind "port"), timed on this box's host cores on a
+                bounded sample of the same pairs.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG = 0.2507          # algorithmic HBM bytes per cell update (SURVEY.md 8d / BASELINE.md section 4)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(length, band, first_pair, budget_pairs):
+    """Times the CPU path on `budget_pairs` pairs with all host cores. Test infrastructure (oracle/) is
+    used here only as the thing being timed for the reported baseline -- never by the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from gam_ngs_amd import api
+    # the reference allocates a 410 MB matrix per in-flight 50 kb pair: cap the pool so the host stays safe
+    threads = min(os.cpu_count() or 1, 16)
+    ref = O.ref()
+    if ref is not None and hasattr(ref, "gamref_bench_pairs"):
+        pairs = [api.synth_pair(first_pair + k, length) for k in range(budget_pairs)]
+        a = [api.decode(m).encode() for m, _ in pairs]
+        b = [api.decode(s).encode() for _, s in pairs]
+        arr_a = (C.c_char_p * budget_pairs)(*a)
+        arr_b = (C.c_char_p * budget_pairs)(*b)
+        la = (C.c_uint64 * budget_pairs)(*[len(x) for x in a])
+        lb = (C.c_uint64 * budget_pairs)(*[len(x) for x in b])
+        ref.gamref_bench_pairs.restype = C.c_uint64
+        ref.gamref_bench_pairs.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p),
+                                           C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        t0 = time.time()
+        cells = ref.gamref_bench_pairs(arr_a, la, arr_b, lb, budget_pairs, band, threads, None)
+        dt = time.time() - t0
+        kind = "reference"
+    else:
+        t0 = time.time()
+        cells = O.oracle().gamdp_oracle_bench_pairs(first_pair, budget_pairs, length, band, threads, None)
+        dt = time.time() - t0
+        kind = "port"
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": threads, "kind": kind,
+            "sample": "%d of the same synthetic %d bp pairs (band %d), %d threads, %.1f s" %
+                      (budget_pairs, length, band, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=16384, help="pairs per GPU per step")
+    ap.add_argument("--len", type=int, default=50000)
+    ap.add_argument("--band", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = 2 per core)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    import gam_ngs_amd as gam
+    from gam_ngs_amd import api, lib as L
+
+    ctx = gam.Context(local_rank)
+    P, length, band = args.pairs, args.len, args.band
+    first = rank * P
+    seqs = []
+    for k in range(P):
+        m, s = api.synth_pair(first + k, length)
+        seqs.append(m)
+        seqs.append(s)
+    sset = gam.SequenceSet(ctx, seqs, ascii=False)
+    tasks = (L.Task * P)()
+    for k in range(P):
+        t = tasks[k]
+        t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, band
+        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, length - 1, 0, len(seqs[2 * k + 1]) - 1
+    out = (L.Result * P)()
+    del seqs
+
+    def step():
+        rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
+        if rc != 0:
+            raise SystemExit("gamdp_align_batch failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_time(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = ctx.kernel_time()
+
+    cells_rank = sum(out[k].cells for k in range(P))
+    bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
+    tt = torch.tensor([dt, float(cells_rank), float(bad)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, cells_all, bad_all = tmax[0].item(), tsum[1].item(), tsum[2].item()
+    else:
+        dt_max, cells_all, bad_all = dt, float(cells_rank), float(bad)
+
+    if rank == 0:
+        gcups = cells_all * args.steps / dt_max / 1e9
+        avg_launch_s = (kernel_ms / 1e3) / max(1, launches)
+        cells_per_launch = cells_rank * args.steps / max(1, launches)
+        achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        line = {
+            "metric": "GCUPS", "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "synthetic %d bp x ~%d bp contig pairs, 5%% divergence, band %d "
+                                   "(BASELINE.json config 5 generator), find_alignment incl. traceback summary"
+                                   % (length, length, band),
+                       "pairs_per_gpu_per_step": P, "cells_per_pair": cells_rank // P,
+                       "parallelism": "pair list statically partitioned over %d GPU(s), no collective" % world,
+                       "failed_pairs": int(bad_all)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_align<17,4,false>", "kernel_ms_per_launch": avg_launch_s * 1e3,
+                         "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
+        }
+        if not args.no_cpu_baseline:
+            n_cpu = args.cpu_pairs or 2 * min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(length, band, first, min(n_cpu, P))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,10 @@
 #include <list>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <utility>
+#include <vector>
 
 #include "alignment/ablast.hpp"
 #include "alignment/banded_smith_waterman.hpp"
@@ -121,6 +124,39 @@ void gamref_normalise(char* s, uint64_t n)
 {
     Contig c = make_contig(s, n);
     for (uint64_t i = 0; i < n; i++) s[i] = char(c.at(i));
+}
+
+
+// CPU-baseline helper for bench.py: n independent find_alignment calls (full windows, no force flags)
+// of the REFERENCE code on `threads` workers pulling from a shared cursor, like the reference's
+// pthread pool (lib/src/pctg/ThreadedBuildPctg.cc:50-74, 143-197).  Returns the total x_size*y_size.
+uint64_t gamref_bench_pairs(const char* const* a, const uint64_t* alen, const char* const* b, const uint64_t* blen,
+                            uint64_t n, uint64_t band, int threads, gamref_result* results)
+{
+    std::vector<Contig> ca, cb;
+    for (uint64_t i = 0; i < n; i++) { ca.push_back(make_contig(a[i], alen[i])); cb.push_back(make_contig(b[i], blen[i])); }
+    std::atomic<uint64_t> cursor(0), cells(0);
+    auto worker = [&]() {
+        BandedSmithWaterman bsw{BandedSmithWaterman::size_type(band)};
+        for (;;) {
+            const uint64_t k = cursor.fetch_add(1);
+            if (k >= n) break;
+            gamref_result r;
+            std::memset(&r, 0, sizeof(r));
+            try {
+                MyAlignment al = bsw.find_alignment(ca[k], 0, alen[k] - 1, cb[k], 0, blen[k] - 1);
+                summarise(al, &r, nullptr, 0);
+            } catch (...) { r.status = 2; }
+            if (results) results[k] = r;
+            uint64_t x = blen[k] < alen[k] + band ? blen[k] : alen[k] + band;
+            if (x > 500000) x = 500000;
+            cells += x * (2 * band + 1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < (threads < 1 ? 1 : threads); t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    return cells.load();
 }
 
 }  // extern "C"
