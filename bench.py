@@ -94,7 +94,7 @@ def main():
 
     ctx = gam.Context(local_rank)
     P, length, band = args.pairs, args.len, args.band
-    first = rank * P
+    first = rank * P  # static partition of the pair list: rank r owns pairs [r*P, (r+1)*P)
     seqs = []
     for k in range(P):
         m, s = api.synth_pair(first + k, length)
@@ -132,15 +132,8 @@ def main():
 
     cells_rank = sum(out[k].cells for k in range(P))
     bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
-    tt = torch.tensor([dt, float(cells_rank), float(bad)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, cells_all, bad_all = tmax[0].item(), tsum[1].item(), tsum[2].item()
-    else:
-        dt_max, cells_all, bad_all = dt, float(cells_rank), float(bad)
+    from gam_ngs_amd import shard
+    dt_max, cells_all, bad_all = shard.reduce_step_stats(dt, float(cells_rank), float(bad), device="cuda")
 
     if rank == 0:
         gcups = cells_all * args.steps / dt_max / 1e9
@@ -163,7 +156,7 @@ def main():
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
         if not args.no_cpu_baseline:
-            n_cpu = args.cpu_pairs or 2 * min(os.cpu_count() or 1, 16)
+            n_cpu = args.cpu_pairs or 8 * min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(length, band, first, min(n_cpu, P))
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,91 @@
+"""Full-size checks on BASELINE.json's workload shape (50 kb x 50 kb pairs, band 512 and the live
+band 150) through size-independent properties of a correct banded alignment, plus spot checks against
+the oracle:
+  * the edit string re-scores to the reported score (5 / -4 / -8; these pairs start at (0,0) so the
+    row-0 gap-free rule does not enter), consumes exactly [begin_a, end] x [begin_b, end] and its
+    MATCH count / first / last MATCH positions equal the reported ones;
+  * summary-only traceback (run-skipping) == edit-string traceback;
+  * results do not depend on batch composition, order or repetition (work-queue scheduling);
+  * band 150 and band 512 agree whenever the band-150 path stays strictly inside its band.
+"""
+import pytest
+
+import _oracle as O
+from _gpu import ctx
+import gam_ngs_amd as gam
+from gam_ngs_amd import api
+
+pytestmark = pytest.mark.gpu
+N_PAIRS, LEN = 48, 50000
+
+
+def walk(ops, a, b, begin_a, begin_b):
+    pa, pb, score, nm = begin_a, begin_b, 0, 0
+    first = last = None
+    for ch in ops:
+        if ch in "MX":
+            is_match = a[pa] == b[pb] or a[pa] == 4 or b[pb] == 4
+            assert (ch == "M") == is_match
+            score += 5 if a[pa] == b[pb] else (0 if (a[pa] == 4 or b[pb] == 4) else -4)
+            if ch == "M":
+                nm += 1
+                last = (pa, pb)
+                if first is None:
+                    first = (pa, pb)
+            pa += 1
+            pb += 1
+        elif ch == "A":
+            score -= 8
+            pb += 1
+        else:
+            score -= 8
+            pa += 1
+    return pa, pb, score, nm, first, last
+
+
+@pytest.fixture(scope="module")
+def workload():
+    c = ctx()
+    pairs = [api.synth_pair(1000 + k, LEN) for k in range(N_PAIRS)]
+    seqs = [x for p in pairs for x in p]
+    sset = gam.SequenceSet(c, seqs, ascii=False)
+    calls = [(sset.contig(2 * k), 0, LEN - 1, sset.contig(2 * k + 1), 0, len(pairs[k][1]) - 1) for k in range(N_PAIRS)]
+    return c, pairs, sset, calls
+
+
+def test_edit_strings_are_self_consistent(workload):
+    c, pairs, sset, calls = workload
+    res = gam.BandedSmithWaterman(c, 512).find_alignments(calls, want_ops=True)
+    for (m, s), r in zip(pairs, res):
+        assert r.status == 0 and r.cells == min(len(s), LEN + 512) * 1025
+        pa, pb, score, nm, first, last = walk(r.ops, m, s, r.begin_a(), r.begin_b())
+        assert score == r.score() and nm == r.n_match and len(r.ops) == r.length()
+        assert r.first_found and r.last_found and first == r.first_match and last == r.last_match
+        assert r.homology() == (nm * 100) / len(r.ops)
+        # semi-global: ends on the last row or on a's last base
+        assert pb == len(s) or pa == LEN
+
+
+def test_summary_traceback_equals_ops_traceback_and_is_schedule_independent(workload):
+    c, pairs, sset, calls = workload
+    bsw = gam.BandedSmithWaterman(c, 512)
+    with_ops = bsw.find_alignments(calls, want_ops=True)
+    summary = bsw.find_alignments(calls, want_ops=False)
+    assert [r.key() for r in with_ops] == [r.key() for r in summary]
+    # reversed order, duplicated tasks, odd batch size
+    perm = list(reversed(range(N_PAIRS))) + [0, 1, 2, 0]
+    again = bsw.find_alignments([calls[i] for i in perm], want_ops=False)
+    assert [r.key() for r in again] == [summary[i].key() for i in perm]
+
+
+def test_band150_equals_band512_and_oracle_spot_checks(workload):
+    c, pairs, sset, calls = workload
+    r512 = gam.BandedSmithWaterman(c, 512).find_alignments(calls)
+    r150 = gam.BandedSmithWaterman(c, 150).find_alignments(calls)
+    for a, b in zip(r512, r150):
+        ka, kb = list(a.key()), list(b.key())
+        assert ka == kb  # drift of these pairs stays far below 150 columns
+    for k in (0, 17):
+        m, s = pairs[k]
+        o, _ = O.oracle_align(m, s, 512, 0, LEN - 1, 0, len(s) - 1, want_ops=False)
+        assert r512[k].key() == o.key()

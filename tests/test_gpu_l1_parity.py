@@ -1,0 +1,94 @@
+"""GPU parity of gamdp_align_merge_blocks (round-batched merge-block driver + HIP kernels) against the
+oracle's restatement of PctgBuilder::alignMergeBlock: align_ok / align_rev / m_start..s_end bit for
+bit, same number of DP calls, and every DP call's result identical (audit trail)."""
+import ctypes as C
+
+import pytest
+
+import _l1cases
+import _oracle as O
+from _gpu import ctx
+import gam_ngs_amd as gam
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_mb(sc, band=150, audit_cap=16):
+    m, s = O.encode(sc["master"]), O.encode(sc["slave"])
+    nb = len(sc["blocks"])
+    arr = (O.OracleBlock * max(1, nb))()
+    for k, b in enumerate(sc["blocks"]):
+        arr[k].m_begin, arr[k].m_end, arr[k].s_begin, arr[k].s_end = b[0], b[1], b[2], b[3]
+        arr[k].m_strand, arr[k].s_strand, arr[k].n_reads = b[4].encode(), b[5].encode(), b[6]
+    mb = O.OracleMB()
+    mb.m_ltail, mb.m_rtail, mb.s_ltail, mb.s_rtail = [int(x) for x in sc["tails"]]
+    aud = (O.OracleResult * audit_cap)()
+    O.oracle().gamdp_oracle_align_merge_block(m, len(m), s, len(s), arr, nb, band, C.byref(mb), aud, audit_cap)
+    return mb, [aud[i].key() for i in range(min(audit_cap, mb.n_dp))]
+
+
+def make_mbs(scs):
+    return [gam.MergeBlock(i, i, [gam.Block(*b) for b in sc["blocks"]], *sc["tails"]) for i, sc in enumerate(scs)]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_merge_blocks_match_oracle(seed):
+    c = ctx()
+    scs = _l1cases.scenarios(500 + seed, 60)
+    masters = gam.SequenceSet(c, [sc["master"].encode() for sc in scs])
+    slaves = gam.SequenceSet(c, [sc["slave"].encode() for sc in scs])
+    mbs = make_mbs(scs)
+    gam.PctgBuilder(c, masters, slaves).alignMergeBlocks(mbs, audit=16)
+    stats = {"ok": 0, "rev": 0, "bad": 0, "tails": 0}
+    for sc, mb in zip(scs, mbs):
+        o, oaud = oracle_mb(sc)
+        got = (mb.status, mb.align_ok, mb.coords_set, mb.n_dp, mb.cells)
+        want = (o.status, bool(o.align_ok), bool(o.touched), o.n_dp, o.cells)
+        assert got == want, (sc["kind"], got, want)
+        if o.touched:
+            assert (mb.align_rev, mb.m_start, mb.m_end, mb.s_start, mb.s_end) == \
+                   (bool(o.align_rev), o.m_start, o.m_end, o.s_start, o.s_end), sc["kind"]
+        assert [a.key() for a in mb.audit] == oaud, sc["kind"]
+        stats["ok"] += mb.align_ok
+        stats["rev"] += mb.align_ok and mb.align_rev
+        stats["bad"] += not mb.align_ok
+        stats["tails"] += mb.align_ok and mb.n_dp > len(sc["blocks"])
+    # the generator must exercise every branch of the driver
+    assert stats["ok"] >= 15 and stats["rev"] >= 3 and stats["bad"] >= 5 and stats["tails"] >= 5, stats
+
+
+def test_single_merge_block_calls_match_batched():
+    c = ctx()
+    scs = _l1cases.scenarios(77, 6)
+    masters = gam.SequenceSet(c, [sc["master"].encode() for sc in scs])
+    slaves = gam.SequenceSet(c, [sc["slave"].encode() for sc in scs])
+    pb = gam.PctgBuilder(c, masters, slaves)
+    batched = pb.alignMergeBlocks(make_mbs(scs))
+    for i, sc in enumerate(scs):
+        one = pb.alignMergeBlock(make_mbs(scs)[i])
+        b = batched[i]
+        assert (one.align_ok, one.align_rev, one.m_start, one.m_end, one.s_start, one.s_end, one.n_dp) == \
+               (b.align_ok, b.align_rev, b.m_start, b.m_end, b.s_start, b.s_end, b.n_dp)
+
+
+def test_reference_exception_is_reported_per_merge_block():
+    """A frame running past the master's end on unrelated sequences makes find_alignment pick a zero cell
+    outside `a`: the reference throws and gam-merge drops the graph.  The driver must
+    report OUT_OF_RANGE for that merge block only."""
+    import random
+    import _cases
+    rng = random.Random(9)
+    c = ctx()
+    m0, s0 = _cases.rand_seq(rng, 300), _cases.rand_seq(rng, 300)
+    good = _l1cases.scenario(random.Random(4), "overlap")
+    masters = gam.SequenceSet(c, [m0.encode(), good["master"].encode()])
+    slaves = gam.SequenceSet(c, [s0.encode(), good["slave"].encode()])
+    scs = [dict(master=m0, slave=s0, blocks=[(250, 400, 10, 160, "+", "+", 9)], tails=(True, True, True, True)), good]
+    mbs = make_mbs(scs)
+    gam.PctgBuilder(c, masters, slaves, band=5).alignMergeBlocks(mbs, audit=8)
+    o0, _ = oracle_mb(scs[0], band=5)
+    assert o0.status == O.OUT_OF_RANGE
+    assert mbs[0].status == O.OUT_OF_RANGE and not mbs[0].align_ok and not mbs[0].coords_set
+    o1, aud1 = oracle_mb(scs[1], band=5)
+    assert (mbs[1].status, mbs[1].align_ok, mbs[1].n_dp) == (o1.status, bool(o1.align_ok), o1.n_dp)
+    assert [a.key() for a in mbs[1].audit] == aud1
