@@ -35,7 +35,8 @@ struct DevTask {
     u64 ops_cap;
 };
 
-enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4 };
+enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4,
+             TF_DIAG_SKIP_TRACEBACK = 8 /* timing diagnostics only (GAMDP_DIAG_SKIP_TRACEBACK=1): results invalid */ };
 
 struct DevResult {
     int32_t begin_a, begin_b;

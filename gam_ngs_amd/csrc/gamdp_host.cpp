@@ -291,6 +291,7 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         for (auto& p : need) { int rc_ = p.first->ensure_rc(p.second); if (rc_) return rc_; }
     }
 
+    static const bool diag_skip_tb = std::getenv("GAMDP_DIAG_SKIP_TRACEBACK") != nullptr;
     std::vector<Prepared> prep(n);
     std::vector<std::vector<u32>> groups(K_COUNT);
     u64 ops_total = 0;
@@ -303,6 +304,7 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             continue;
         }
         prep[i].dt.res_idx = (u32)i;
+        if (diag_skip_tb) prep[i].dt.flags |= TF_DIAG_SKIP_TRACEBACK;
         if (ops && ops->ops_buf && ops->ops_cap[i] > 0) {
             prep[i].dt.flags |= TF_WANT_OPS;
             prep[i].dt.ops_off = ops_total;

@@ -40,20 +40,29 @@ constexpr int FORCE_MAXGAP = 10;
 
 enum { ST_OK = 0, ST_EMPTY = 1, ST_OUT_OF_RANGE = 2 };
 
+// All buffers live in HBM: tell the compiler (pointers read from DevTask/LaunchParams would otherwise be
+// "flat" and every access would tie up both the vector-memory and the LDS counters).
+typedef const __attribute__((address_space(1))) u32* gcptr;
+typedef __attribute__((address_space(1))) u32* gptr;
+typedef __attribute__((address_space(1))) int* giptr;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4* g4ptr;
+__device__ __forceinline__ gcptr as_global(const u32* p) { return (gcptr)p; }
+
 // ---- packed sequence access ---------------------------------------------------------------------
-__device__ __forceinline__ u32 fetch16(const u32* __restrict__ p2, int64_t idx)
+__device__ __forceinline__ u32 fetch16(gcptr p2, int64_t idx)
 {  // 16 bases starting at base idx (any alignment, idx may be negative: pads)
     const int64_t w = idx >> 4;
     const u32 sh = (u32)(idx & 15) * 2u;
     return __builtin_amdgcn_alignbit(p2[w + 1], p2[w], sh);
 }
-__device__ __forceinline__ u32 fetch16n(const u32* __restrict__ pn, int64_t idx)
+__device__ __forceinline__ u32 fetch16n(gcptr pn, int64_t idx)
 {
     const int64_t w = idx >> 5;
     const u32 sh = (u32)(idx & 31);
     return __builtin_amdgcn_alignbit(pn[w + 1], pn[w], sh) & 0xFFFFu;
 }
-__device__ __forceinline__ int code_at(const u32* __restrict__ p2, const u32* __restrict__ pn, int64_t idx)
+__device__ __forceinline__ int code_at(gcptr p2, gcptr pn, int64_t idx)
 {
     const int n = (pn[idx >> 5] >> (idx & 31)) & 1;
     const int c = (p2[idx >> 4] >> ((idx & 15) * 2)) & 3;
@@ -73,15 +82,41 @@ __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b)
 
 // uniform per-task values
 struct Tk {
-    const u32 *a2, *an, *b2, *bn;
+    gcptr a2, an, b2, bn;
     int64_t a_base, b_base, end_a;
     int alen, blen, begin_a, begin_b, X, band, Y;
     bool fs, fe;
     int iA;       // first row of the pos==end_a anti-diagonal scan (:192)
     int eaRel;    // end_a - begin_a + band clamped to int: band column of pos==end_a in row 0
-    u32* dir;
-    int *h0row, *pos0, *lastrow, *adh;
+    gptr dir;
+    giptr h0row, pos0, lastrow, adh;
 };
+
+
+// Out-of-line device functions receive their arguments in vector registers, so the compiler has to assume
+// they differ per lane.  Everything in Tk is wave-uniform: re-assert that (v_readfirstlane) once per call so
+// that the callee computes addresses, loop counters and the whole traceback walk on the scalar unit.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)v);
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((u64)v >> 32));
+    return (int64_t)(((u64)hi << 32) | lo);
+}
+template <class P>
+__device__ __forceinline__ P unip(P p) { return (P)(u64)uni64((int64_t)(u64)p); }
+__device__ __forceinline__ Tk load_uniform(const Tk* tp)
+{
+    Tk t = *tp;
+    t.a2 = unip(t.a2); t.an = unip(t.an); t.b2 = unip(t.b2); t.bn = unip(t.bn);
+    t.a_base = uni64(t.a_base); t.b_base = uni64(t.b_base); t.end_a = uni64(t.end_a);
+    t.alen = uni(t.alen); t.blen = uni(t.blen); t.begin_a = uni(t.begin_a); t.begin_b = uni(t.begin_b);
+    t.X = uni(t.X); t.band = uni(t.band); t.Y = uni(t.Y);
+    t.fs = uni(t.fs) != 0; t.fe = uni(t.fe) != 0;
+    t.iA = uni(t.iA); t.eaRel = uni(t.eaRel);
+    t.dir = unip(t.dir); t.h0row = unip(t.h0row); t.pos0 = unip(t.pos0); t.lastrow = unip(t.lastrow); t.adh = unip(t.adh);
+    return t;
+}
 
 template <int C>
 __device__ __forceinline__ u64 dir_index(int blk, int lane, int c)
@@ -95,17 +130,10 @@ __device__ __forceinline__ u64 dir_index(int blk, int lane, int c)
 // ---- one block of 16 row-times --------------------------------------------------------------------
 template <int C, int CE, bool HASN, bool SLOW>
 __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, const Tk& t,
-                                         const int blk, const int lane, const int LE, const int kill_c)
+                                         const int blk, const int lane, const int LE, const int kill_c,
+                                         const u32 abits, const u32 bbits, const u32 anb, const u32 bnb)
 {
     const int tau0 = blk * ROWS;
-    const int64_t sA = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1) + tau0;
-    const int64_t sB = t.b_base + t.begin_b + tau0 - lane;
-    const u32 abits = fetch16(t.a2, sA), bbits = fetch16(t.b2, sB);
-    u32 anb = 0, bnb = 0;
-    if (HASN) {
-        anb = fetch16n(t.an, sA);
-        bnb = fetch16n(t.bn, sB);
-    }
 
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -196,11 +224,11 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     // direction words of this block: 16 B / lane coalesced
     {
         constexpr int G = C / 4, REM = C % 4;
-        u32* blkp = t.dir + (u64)blk * (u64)(C * 64);
+        gptr blkp = t.dir + (u64)blk * (u64)(C * 64);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            uint4 v = make_uint4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-            *reinterpret_cast<uint4*>(blkp + g * 256 + lane * 4) = v;
+            u32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *(g4ptr)(blkp + g * 256 + lane * 4) = v;
         }
 #pragma unroll
         for (int e = 0; e < REM; ++e) blkp[G * 256 + lane * REM + e] = acc[4 * G + e];
@@ -210,34 +238,360 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     for (int k = 0; k < C - 1; ++k) W[k] = W[k + ROWS];
 }
 
-// ---- the whole task -------------------------------------------------------------------------------
-template <int C, int CE, bool HASN>
-__device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane)
-{
-    Tk t;
-    t.a2 = dt.a2; t.an = dt.an; t.b2 = dt.b2; t.bn = dt.bn;
-    t.a_base = dt.a_base; t.b_base = dt.b_base; t.end_a = dt.end_a;
-    t.alen = dt.alen; t.blen = dt.blen; t.begin_a = dt.begin_a; t.begin_b = dt.begin_b;
-    t.X = dt.X; t.band = dt.band; t.Y = 2 * dt.band + 1;
-    t.fs = dt.flags & TF_FORCE_START; t.fe = dt.flags & TF_FORCE_END;
-    t.dir = slot;
-    t.h0row = reinterpret_cast<int*>(slot + p.dir_words);
-    t.pos0 = t.h0row + p.ypad;
-    t.lastrow = t.pos0 + p.ypad;
-    t.adh = t.lastrow + p.ypad;
-    {
-        const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
-        t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
-        const bool ge = t.end_a >= (int64_t)t.begin_a + t.band;
-        const int64_t ia = ge ? t.end_a - ((int64_t)t.begin_a + t.band) : 0;
-        t.iA = (int)min(ia, (int64_t)(1 << 30));
-    }
-    const int X = t.X, Y = t.Y, w = t.band;
-    const int LE = (Y - 1) / C;                              // lane holding the last band column
-    const int ce_rt = (Y - 1) % C;
-    const int kill_c = (CE < 0 && lane == LE) ? ce_rt : -1;  // generic kernels: runtime edge column
+template <int C>
+struct BlockState {
+    int Lp[C];
+    u32 acc[C];
+    u32 W[C + 15];
+    int Lin;
+};
 
-    // ---- phase A: row 0 (:112-132): running max without gap penalty along j --------------------------
+// The fill is driven through three out-of-line functions that hand the per-lane register state over in a
+// BlockState (private memory): init_row0 (phase A), slow_block (one block of the top-left triangle / ramp-up /
+// anti-diagonal and last-row capture region: 2 % of the blocks of a 50 kb pair) and fast_range (a run of
+// consecutive plain blocks -- the hot loop).  Keeping them separate functions gives the hot loop its own
+// register allocation: nothing live in the other phases can force a spill (and with it a full
+// `s_waitcnt vmcnt(0)` drain of the outstanding direction stores) into it.
+template <int C>
+__device__ __forceinline__ void load_state(const BlockState<C>* st, int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin)
+{
+#pragma unroll
+    for (int c = 0; c < C; ++c) { Lp[c] = st->Lp[c]; acc[c] = st->acc[c]; }
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k) W[k] = st->W[k];
+#pragma unroll
+    for (int k = C - 1; k < C + 15; ++k) W[k] = 0;
+    Lin = st->Lin;
+}
+template <int C>
+__device__ __forceinline__ void store_state(BlockState<C>* st, const int (&Lp)[C], const u32 (&acc)[C], const u32 (&W)[C + 15], const int Lin)
+{
+#pragma unroll
+    for (int c = 0; c < C; ++c) { st->Lp[c] = Lp[c]; st->acc[c] = acc[c]; }
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k) st->W[k] = W[k];
+    st->Lin = Lin;
+}
+
+template <int C, int CE, bool HASN>
+__device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const int blk_, const int lane)
+{
+    const Tk t = load_uniform(tp);
+    const int blk = uni(blk_);
+    const int LE = (t.Y - 1) / C;
+    const int kill_c = (CE < 0 && lane == LE) ? (t.Y - 1) % C : -1;
+    int Lp[C];
+    u32 acc[C];
+    u32 W[C + 15];
+    int Lin;
+    load_state<C>(st, Lp, acc, W, Lin);
+    const int64_t sA = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1) + blk * ROWS;
+    const int64_t sB = t.b_base + t.begin_b - lane + blk * ROWS;
+    const u32 abits = fetch16(t.a2, sA), bbits = fetch16(t.b2, sB);
+    const u32 anb = HASN ? fetch16n(t.an, sA) : 0u, bnb = HASN ? fetch16n(t.bn, sB) : 0u;
+    do_block<C, CE, HASN, true>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
+    store_state<C>(st, Lp, acc, W, Lin);
+}
+
+// blocks [blk_begin, blk_end) are all "fast": every lane is past row 0, no pos <= 0 cell, no capture row
+template <int C, int CE, bool HASN>
+__device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const int blk_begin_, const int blk_end_, const int lane)
+{
+    const Tk t = load_uniform(tp);
+    const int blk_begin = uni(blk_begin_), blk_end = uni(blk_end_);
+    const int LE = (t.Y - 1) / C;
+    const int kill_c = (CE < 0 && lane == LE) ? (t.Y - 1) % C : -1;
+    int Lp[C];
+    u32 acc[C];
+    u32 W[C + 15];
+    int Lin;
+    load_state<C>(st, Lp, acc, W, Lin);
+    // Per-lane sequence streams advance exactly 16 bases (= one 2-bit word) per block, so each block needs one
+    // new word per stream; it is requested one block ahead and only waited for at the top of the next block.
+    const int64_t sA0 = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1);  // base index of block 0
+    const int64_t sB0 = t.b_base + t.begin_b - lane;
+    gcptr pa = t.a2 + (sA0 >> 4), pb = t.b2 + (sB0 >> 4);
+    const u32 sha = (u32)(sA0 & 15) * 2u, shb = (u32)(sB0 & 15) * 2u;
+    u32 a_lo = pa[blk_begin], a_hi = pa[blk_begin + 1], b_lo = pb[blk_begin], b_hi = pb[blk_begin + 1];
+    // N planes (32 bases per word): two words per block, also one block ahead
+    u32 an_lo = 0, an_hi = 0, bn_lo = 0, bn_hi = 0;
+    if (HASN) {
+        const int64_t ia = sA0 + (int64_t)blk_begin * ROWS, ib = sB0 + (int64_t)blk_begin * ROWS;
+        an_lo = t.an[ia >> 5]; an_hi = t.an[(ia >> 5) + 1];
+        bn_lo = t.bn[ib >> 5]; bn_hi = t.bn[(ib >> 5) + 1];
+    }
+    for (int blk = blk_begin; blk < blk_end; ++blk) {
+        const int tau0 = blk * ROWS;
+        const u32 a_nx = pa[blk + 2], b_nx = pb[blk + 2];  // prefetch for block blk+1
+        u32 an_lo_nx = 0, an_hi_nx = 0, bn_lo_nx = 0, bn_hi_nx = 0;
+        if (HASN) {
+            const int64_t ia = sA0 + tau0 + ROWS, ib = sB0 + tau0 + ROWS;
+            an_lo_nx = t.an[ia >> 5]; an_hi_nx = t.an[(ia >> 5) + 1];
+            bn_lo_nx = t.bn[ib >> 5]; bn_hi_nx = t.bn[(ib >> 5) + 1];
+        }
+        const u32 abits = __builtin_amdgcn_alignbit(a_hi, a_lo, sha);
+        const u32 bbits = __builtin_amdgcn_alignbit(b_hi, b_lo, shb);
+        u32 anb = 0, bnb = 0;
+        if (HASN) {
+            anb = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((sA0 + tau0) & 31)) & 0xFFFFu;
+            bnb = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((sB0 + tau0) & 31)) & 0xFFFFu;
+        }
+        do_block<C, CE, HASN, false>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
+        a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
+        if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
+    }
+    store_state<C>(st, Lp, acc, W, Lin);
+}
+
+// ---- phases C + D: end-cell search and traceback ------------------------------------------------------
+// Kept out of line (like the slow block) so that its registers -- and the scalar registers holding its many
+// compare masks -- are allocated separately from the hot fill loop.
+template <int C, bool HASN>
+__device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, const LaunchParams* pp, const int lane)
+{
+    const Tk t = load_uniform(tp);
+    const DevTask* dtp = unip(dtp_);
+    const u32 dt_flags = (u32)uni((int)dtp->flags), dt_res_idx = (u32)uni((int)dtp->res_idx);
+    const u64 dt_ops_off = (u64)uni64((int64_t)dtp->ops_off), dt_ops_cap = (u64)uni64((int64_t)dtp->ops_cap);
+    uint8_t* const p_ops_buf = unip(pp->ops_buf);
+    DevResult* const p_results = unip(pp->results);
+    const int X = t.X, Y = t.Y, w = t.band;
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines cached by the slot's previous task
+
+    // ---- phase C: end cell (:174-212), first maximum in scan order wins --------------------------------
+    int best = NEG, bkey = 0x7fffffff;  // key = scan position
+    {
+        const giptr lr = (X == 1) ? t.h0row : t.lastrow;
+        if (!t.fe) {
+            for (int j = lane; j < Y; j += 64) {
+                const int64_t pos = (int64_t)t.begin_a + (X - 1) + j - w;
+                if (pos >= 0 && pos <= t.end_a) {
+                    const int v = (pos < t.alen) ? lr[j] : 0;  // cells outside a keep their zero
+                    if (v > best || (v == best && j < bkey)) { best = v; bkey = j; }
+                }
+            }
+        }
+        // anti-diagonal pos == end_a: cells (iA + k, jA - k)
+        const bool ge = t.end_a >= (int64_t)t.begin_a + w;
+        const int64_t jA64 = ge ? (int64_t)2 * w : (int64_t)2 * w - ((int64_t)t.begin_a + w - t.end_a);
+        if (jA64 >= 0 && t.iA < X) {
+            const int jA = (int)jA64;
+            const int cnt = min(X - t.iA, jA + 1);
+            for (int k = lane; k < cnt; k += 64) {
+                const int i = t.iA + k, j = jA - k;
+                bool ok = true;
+                if (t.fe) ok = (X >= FORCE_MAXGAP + 1) && (i >= X - 1 - FORCE_MAXGAP);  // unsigned compare in the reference
+                if (ok) {
+                    int v = 0;
+                    if (t.end_a < t.alen) v = (i == 0) ? t.h0row[j] : ((i == X - 1) ? lr[j] : t.adh[k]);
+                    const int key = Y + k;
+                    if (v > best || (v == best && key < bkey)) { best = v; bkey = key; }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int ov = __shfl_xor(best, o, 64), ok = __shfl_xor(bkey, o, 64);
+            if (ov > best || (ov == best && ok < bkey)) { best = ov; bkey = ok; }
+        }
+    }
+
+    DevResult res;
+    res.begin_a = res.begin_b = res.score = 0;
+    res.n_match = res.length = 0;
+    res.first_a = res.first_b = res.last_a = res.last_b = 0;
+    res.flags = ST_EMPTY << 8;
+    // after the wave reduction every lane holds the same (best, bkey): make that explicit so that the whole
+    // walk below is scalar code (SALU) and does not take vector-issue slots from the waves still filling
+    best = __builtin_amdgcn_readfirstlane(best);
+    bkey = __builtin_amdgcn_readfirstlane(bkey);
+    if (bkey != 0x7fffffff) {
+        int x, y;
+        if (bkey < Y) { x = X - 1; y = bkey; }
+        else {
+            const bool ge = t.end_a >= (int64_t)t.begin_a + w;
+            const int jA = ge ? 2 * w : (int)((int64_t)2 * w - ((int64_t)t.begin_a + w - t.end_a));
+            x = t.iA + (bkey - Y);
+            y = jA - (bkey - Y);
+        }
+        int64_t pos64 = (int64_t)t.begin_a + x + y - w;
+        if (pos64 >= t.alen) {
+            res.flags = ST_OUT_OF_RANGE << 8;  // reference: a.at(pos) throws in the traceback
+        } else {
+            // ---- phase D: traceback (:217-311) ------------------------------------------------------------
+            int pos = (int)pos64;
+            const int end_pos = pos, end_x = x;
+            const bool want_ops = dt_flags & TF_WANT_OPS;
+            uint8_t* ops = p_ops_buf + dt_ops_off;
+            u32 len = 0, nm = 0;
+            bool have_last = false, have_first = false;
+            int la = 0, lb = 0, fa = 0, fb = 0;
+            int l = y / C, c = y - l * C;
+            // Direction-word cache for the walk: lane k (< TB_DEPTH) holds, for block (cblk0 - k), the 4-column
+            // group `cg` of lane-row `cl`.  A diagonal run stays in one (lane-row, column) and walks down the
+            // blocks, a gap moves one column sideways (3 times out of 4 inside the same group), so one refill
+            // (one 16 B load per lane, all in flight together) serves several dependent steps of the walk.
+            constexpr int TB_DEPTH = 16;
+            int cblk0 = -1, cl = -1, cg = -1;
+            u32 cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
+            // Packed-sequence window for the match counting: lane k holds 2-bit word (w0 - k); the walk moves towards
+            // lower indices, so one refill (one coalesced 256 B load) covers the next ~1000 bases.
+            int64_t sa_w0 = INT64_MIN, sb_w0 = INT64_MIN;
+            u32 sa_v = 0, sb_v = 0;
+            auto seq16 = [&](gcptr plane, const int64_t idx, int64_t& w0, u32& v) -> u32 {
+                const int64_t wlo = idx >> 4;
+                if (wlo + 1 > w0 || wlo < w0 - 63) {
+                    w0 = wlo + 1;
+                    v = plane[w0 - lane];
+                }
+                const int k = __builtin_amdgcn_readfirstlane((int)(w0 - wlo));
+                const u32 lo = (u32)__builtin_amdgcn_readlane((int)v, k), hi = (u32)__builtin_amdgcn_readlane((int)v, k - 1);
+                return __builtin_amdgcn_alignbit(hi, lo, (u32)(idx & 15) * 2u);
+            };
+            auto get_word = [&](const int blk, const int l_, const int c_) -> u32 {
+                constexpr int G = C / 4;
+                const int g = c_ >> 2;
+                int k = cblk0 - blk;
+                if (l_ != cl || g != cg || k < 0 || k >= TB_DEPTH) {
+                    cblk0 = blk; cl = l_; cg = g; k = 0;
+                    // no lane-dependent branch here (it would make the compiler treat the whole walk as
+                    // divergent): lanes >= TB_DEPTH and blocks below 0 just re-read a neighbour's address
+                    const int myblk = max(blk - min(lane, TB_DEPTH - 1), 0);
+                    if (g < G) {
+                        const u32x4 v = *(g4ptr)(t.dir + dir_index<C>(myblk, l_, 4 * g));
+                        cv0 = v.x; cv1 = v.y; cv2 = v.z; cv3 = v.w;
+                    } else {
+                        cv0 = t.dir[dir_index<C>(myblk, l_, 4 * G)];
+                        if (C % 4 > 1) cv1 = t.dir[dir_index<C>(myblk, l_, (C % 4 > 1) ? 4 * G + 1 : 4 * G)];
+                        if (C % 4 > 2) cv2 = t.dir[dir_index<C>(myblk, l_, (C % 4 > 2) ? 4 * G + 2 : 4 * G)];
+                    }
+                }
+                const int e = c_ & 3;
+                const u32 sel = (e == 0) ? cv0 : (e == 1) ? cv1 : (e == 2) ? cv2 : cv3;
+                return (u32)__builtin_amdgcn_readlane((int)sel, __builtin_amdgcn_readfirstlane(k));
+            };
+            if (dt_flags & TF_DIAG_SKIP_TRACEBACK) x = -1;
+            while (x >= 0 && y >= 0 && pos >= 0) {
+                // the walk state is wave-uniform by construction; pin it to scalar registers every iteration so
+                // the body is selected as SALU code whatever the divergence analysis concluded about the loop
+                x = uni(x); y = uni(y); pos = uni(pos); l = uni(l); c = uni(c);
+                cblk0 = uni(cblk0); cl = uni(cl); cg = uni(cg);
+                sa_w0 = uni64(sa_w0); sb_w0 = uni64(sb_w0);
+                if (x == 0 || pos == 0 || want_ops) {
+                    // single step with the reference's exact rules
+                    const int pa = HASN ? code_at(t.a2, t.an, t.a_base + pos) : (int)((t.a2[(t.a_base + pos) >> 4] >> (((t.a_base + pos) & 15) * 2)) & 3);
+                    const int64_t bi = t.b_base + t.begin_b + x;
+                    const int pb = HASN ? code_at(t.b2, t.bn, bi) : (int)((t.b2[bi >> 4] >> ((bi & 15) * 2)) & 3);
+                    const bool is_match = (pa == pb) || pa == 4 || pb == 4;
+                    int op;  // 0 GAP_A, 1 GAP_B, 2 diag
+                    if (pos == 0) {
+                        const int s = score_of(pa, pb);
+                        const int h = (x == 0) ? t.h0row[y] : t.pos0[x];
+                        const bool left_ok = !(t.fs && x > FORCE_MAXGAP);
+                        if (h == s) op = 2;
+                        else if (y == Y - 1 || (left_ok && h == GAP)) op = 1;
+                        else op = 0;
+                    } else if (x == 0) {
+                        const int s = score_of(pa, pb);
+                        const int h = t.h0row[y];
+                        const bool up_ok = !(t.fs && pos > FORCE_MAXGAP);
+                        if (h == s) op = 2;
+                        else if (y < Y - 1 && y > 0 && up_ok && h == GAP) op = 0;
+                        else if (y < Y - 1 && y > 0) op = 1;
+                        else if (y < Y - 1) op = 0;
+                        else op = 1;
+                    } else {
+                        const int tau = x + l, blk = tau >> 4;
+                        const u32 cw = get_word(blk, l, c);
+                        const u32 tag = (cw >> ((tau & 15) * 2)) & 3u;
+                        op = (tag == 2u) ? 2 : (tag == 1u ? 0 : 1);
+                    }
+                    if (op == 2) {
+                        if (is_match) {
+                            nm++;
+                            if (!have_last) { have_last = true; la = pos; lb = t.begin_b + x; }
+                            have_first = true; fa = pos; fb = t.begin_b + x;
+                        }
+                        if (want_ops && len < dt_ops_cap) ops[len] = is_match ? 2 : 3;
+                        x--; pos--;
+                    } else if (op == 1) {  // GAP_B: consumes a
+                        if (want_ops && len < dt_ops_cap) ops[len] = 1;
+                        y--; pos--;
+                        if (--c < 0) { c = C - 1; l--; }
+                    } else {  // GAP_A: consumes b
+                        if (want_ops && len < dt_ops_cap) ops[len] = 0;
+                        x--; y++;
+                        if (++c == C) { c = 0; l++; }
+                    }
+                    len++;
+                } else {
+                    // interior: consume a whole run of diagonal steps from one direction word
+                    const int tau = x + l, blk = tau >> 4, r = tau & 15;
+                    const u32 cw = get_word(blk, l, c);
+                    const u32 T = (cw ^ 0xAAAAAAAAu) << (30 - 2 * r);  // pair r on top; diag pairs are 00
+                    int n = T ? (__builtin_clz(T) >> 1) : (r + 1);
+                    n = min(n, min(x, pos));  // stay in x >= 1, pos >= 1
+                    if (n > 0) {
+                        const int64_t ia = t.a_base + pos - n + 1, ib = t.b_base + t.begin_b + x - n + 1;
+                        const u32 xr = seq16(t.a2, ia, sa_w0, sa_v) ^ seq16(t.b2, ib, sb_w0, sb_v);
+                        u32 ne = (xr | (xr >> 1)) & 0x55555555u;  // bit 2k set: bases k differ
+                        if (HASN) {
+                            u32 nn = fetch16n(t.an, ia) | fetch16n(t.bn, ib);  // either is N -> MATCH
+                            // spread 16 bits to even positions
+                            nn = (nn | (nn << 8)) & 0x00FF00FFu;
+                            nn = (nn | (nn << 4)) & 0x0F0F0F0Fu;
+                            nn = (nn | (nn << 2)) & 0x33333333u;
+                            nn = (nn | (nn << 1)) & 0x55555555u;
+                            ne &= ~nn;
+                        }
+                        const u32 msk = (n == 16) ? 0x55555555u : (((1u << (2 * n)) - 1u) & 0x55555555u);
+                        const u32 eq = ~ne & msk;
+                        if (eq) {
+                            nm += (u32)__builtin_popcount(eq);
+                            const int hi = (31 - __builtin_clz(eq)) >> 1, lo = __builtin_ctz(eq) >> 1;
+                            if (!have_last) { have_last = true; la = pos - n + 1 + hi; lb = t.begin_b + x - n + 1 + hi; }
+                            have_first = true; fa = pos - n + 1 + lo; fb = t.begin_b + x - n + 1 + lo;
+                        }
+                        x -= n; pos -= n; len += (u32)n;
+                    } else {
+                        const u32 tag = (cw >> (r * 2)) & 3u;
+                        if (tag == 1u) {  // GAP_A
+                            x--; y++;
+                            if (++c == C) { c = 0; l++; }
+                        } else {  // GAP_B
+                            y--; pos--;
+                            if (--c < 0) { c = C - 1; l--; }
+                        }
+                        len++;
+                    }
+                }
+            }
+            res.begin_a = pos + 1;
+            res.begin_b = t.begin_b + x + 1;
+            res.score = best;
+            res.n_match = nm;
+            res.length = len;
+            // first_match_pos without a MATCH returns the end coordinates, last_match_pos the begin ones
+            res.first_a = have_first ? fa : end_pos + 1;
+            res.first_b = have_first ? fb : t.begin_b + end_x + 1;
+            res.last_a = have_last ? la : res.begin_a;
+            res.last_b = have_last ? lb : res.begin_b;
+            res.flags = (have_first ? 1u : 0u) | (have_last ? 2u : 0u) | (ST_OK << 8);
+        }
+    }
+    if (lane == 0) p_results[dt_res_idx] = res;
+    __syncthreads();
+}
+
+// ---- phase A: row 0 -----------------------------------------------------------------------------------
+template <int C, bool HASN>
+__device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const int lane)
+{
+    const Tk t = load_uniform(tp);
+    const int Y = t.Y, w = t.band;
+    const int LE = (Y - 1) / C;
+    // row 0 (:112-132): running max without gap penalty along j
     int Lp[C];
     u32 acc[C];
     u32 W[C + 15];
@@ -299,200 +653,56 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
         for (int k = C - 1; k < C + 15; ++k) W[k] = 0;
     }
 
-    // ---- phase B: rows 1..X-1 -------------------------------------------------------------------------
+    store_state<C>(st, Lp, acc, W, Lin);
+}
+
+// ---- the whole task -------------------------------------------------------------------------------
+template <int C, int CE, bool HASN>
+__device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane)
+{
+    Tk t;
+    t.a2 = as_global(dt.a2); t.an = as_global(dt.an); t.b2 = as_global(dt.b2); t.bn = as_global(dt.bn);
+    t.a_base = dt.a_base; t.b_base = dt.b_base; t.end_a = dt.end_a;
+    t.alen = dt.alen; t.blen = dt.blen; t.begin_a = dt.begin_a; t.begin_b = dt.begin_b;
+    t.X = dt.X; t.band = dt.band; t.Y = 2 * dt.band + 1;
+    t.fs = dt.flags & TF_FORCE_START; t.fe = dt.flags & TF_FORCE_END;
+    t.dir = (gptr)slot;
+    t.h0row = (giptr)(slot + p.dir_words);
+    t.pos0 = t.h0row + p.ypad;
+    t.lastrow = t.pos0 + p.ypad;
+    t.adh = t.lastrow + p.ypad;
+    {
+        const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
+        t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
+        const bool ge = t.end_a >= (int64_t)t.begin_a + t.band;
+        const int64_t ia = ge ? t.end_a - ((int64_t)t.begin_a + t.band) : 0;
+        t.iA = (int)min(ia, (int64_t)(1 << 30));
+    }
+    const int X = t.X, w = t.band;
+    const int LE = (t.Y - 1) / C;  // lane holding the last band column
+    BlockState<C> st;
+    init_row0<C, HASN>(&st, &t, lane);
+
+    // ---- phase B: rows 1..X-1 in blocks of 16 row-times ----------------------------------------------------
     const int nblk = (X - 1 + LE) / ROWS + 1;
-    {
-        const int64_t iE0 = t.end_a - t.begin_a - w, iE1 = t.end_a - t.begin_a + w;
-        for (int blk = 0; blk < nblk; ++blk) {
-            const int tau0 = blk * ROWS;
-            const bool fast = (tau0 - LE >= 1) && (t.begin_a - w + tau0 >= 1) && (tau0 + ROWS - 1 < X - 1) &&
-                              ((int64_t)(tau0 + ROWS - 1) < iE0 || (int64_t)(tau0 - LE) > iE1);
-            if (fast) do_block<C, CE, HASN, false>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c);
-            else do_block<C, CE, HASN, true>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c);
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines cached by the slot's previous task
-
-    // ---- phase C: end cell (:174-212), first maximum in scan order wins --------------------------------
-    int best = NEG, bkey = 0x7fffffff;  // key = scan position
-    {
-        const int* lr = (X == 1) ? t.h0row : t.lastrow;
-        if (!t.fe) {
-            for (int j = lane; j < Y; j += 64) {
-                const int64_t pos = (int64_t)t.begin_a + (X - 1) + j - w;
-                if (pos >= 0 && pos <= t.end_a) {
-                    const int v = (pos < t.alen) ? lr[j] : 0;  // cells outside a keep their zero
-                    if (v > best || (v == best && j < bkey)) { best = v; bkey = j; }
-                }
-            }
-        }
-        // anti-diagonal pos == end_a: cells (iA + k, jA - k)
-        const bool ge = t.end_a >= (int64_t)t.begin_a + w;
-        const int64_t jA64 = ge ? (int64_t)2 * w : (int64_t)2 * w - ((int64_t)t.begin_a + w - t.end_a);
-        if (jA64 >= 0 && t.iA < X) {
-            const int jA = (int)jA64;
-            const int cnt = min(X - t.iA, jA + 1);
-            for (int k = lane; k < cnt; k += 64) {
-                const int i = t.iA + k, j = jA - k;
-                bool ok = true;
-                if (t.fe) ok = (X >= FORCE_MAXGAP + 1) && (i >= X - 1 - FORCE_MAXGAP);  // unsigned compare in the reference
-                if (ok) {
-                    int v = 0;
-                    if (t.end_a < t.alen) v = (i == 0) ? t.h0row[j] : ((i == X - 1) ? lr[j] : t.adh[k]);
-                    const int key = Y + k;
-                    if (v > best || (v == best && key < bkey)) { best = v; bkey = key; }
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const int ov = __shfl_xor(best, o, 64), ok = __shfl_xor(bkey, o, 64);
-            if (ov > best || (ov == best && ok < bkey)) { best = ov; bkey = ok; }
-        }
-    }
-
-    DevResult res;
-    res.begin_a = res.begin_b = res.score = 0;
-    res.n_match = res.length = 0;
-    res.first_a = res.first_b = res.last_a = res.last_b = 0;
-    res.flags = ST_EMPTY << 8;
-    if (bkey != 0x7fffffff) {
-        int x, y;
-        if (bkey < Y) { x = X - 1; y = bkey; }
-        else {
-            const bool ge = t.end_a >= (int64_t)t.begin_a + w;
-            const int jA = ge ? 2 * w : (int)((int64_t)2 * w - ((int64_t)t.begin_a + w - t.end_a));
-            x = t.iA + (bkey - Y);
-            y = jA - (bkey - Y);
-        }
-        int64_t pos64 = (int64_t)t.begin_a + x + y - w;
-        if (pos64 >= t.alen) {
-            res.flags = ST_OUT_OF_RANGE << 8;  // reference: a.at(pos) throws in the traceback
+    const int64_t iE0 = t.end_a - t.begin_a - w, iE1 = t.end_a - t.begin_a + w;
+    auto is_fast = [&](const int blk) {
+        const int tau0 = blk * ROWS;
+        return (tau0 - LE >= 1) && (t.begin_a - w + tau0 >= 1) && (tau0 + ROWS - 1 < X - 1) &&
+               ((int64_t)(tau0 + ROWS - 1) < iE0 || (int64_t)(tau0 - LE) > iE1);
+    };
+    for (int blk = 0; blk < nblk;) {
+        if (is_fast(blk)) {
+            int e = blk + 1;
+            while (e < nblk && is_fast(e)) ++e;
+            fast_range<C, CE, HASN>(&st, &t, blk, e, lane);
+            blk = e;
         } else {
-            // ---- phase D: traceback (:217-311) ------------------------------------------------------------
-            int pos = (int)pos64;
-            const int end_pos = pos, end_x = x;
-            const bool want_ops = dt.flags & TF_WANT_OPS;
-            uint8_t* ops = p.ops_buf + dt.ops_off;
-            u32 len = 0, nm = 0;
-            bool have_last = false, have_first = false;
-            int la = 0, lb = 0, fa = 0, fb = 0;
-            int l = y / C, c = y - l * C;
-            // cached direction word
-            int cw_blk = -1, cw_l = -1, cw_c = -1;
-            u32 cw = 0;
-            while (x >= 0 && y >= 0 && pos >= 0) {
-                if (x == 0 || pos == 0 || want_ops) {
-                    // single step with the reference's exact rules
-                    const int pa = HASN ? code_at(t.a2, t.an, t.a_base + pos) : (int)((t.a2[(t.a_base + pos) >> 4] >> (((t.a_base + pos) & 15) * 2)) & 3);
-                    const int64_t bi = t.b_base + t.begin_b + x;
-                    const int pb = HASN ? code_at(t.b2, t.bn, bi) : (int)((t.b2[bi >> 4] >> ((bi & 15) * 2)) & 3);
-                    const bool is_match = (pa == pb) || pa == 4 || pb == 4;
-                    int op;  // 0 GAP_A, 1 GAP_B, 2 diag
-                    if (pos == 0) {
-                        const int s = score_of(pa, pb);
-                        const int h = (x == 0) ? t.h0row[y] : t.pos0[x];
-                        const bool left_ok = !(t.fs && x > FORCE_MAXGAP);
-                        if (h == s) op = 2;
-                        else if (y == Y - 1 || (left_ok && h == GAP)) op = 1;
-                        else op = 0;
-                    } else if (x == 0) {
-                        const int s = score_of(pa, pb);
-                        const int h = t.h0row[y];
-                        const bool up_ok = !(t.fs && pos > FORCE_MAXGAP);
-                        if (h == s) op = 2;
-                        else if (y < Y - 1 && y > 0 && up_ok && h == GAP) op = 0;
-                        else if (y < Y - 1 && y > 0) op = 1;
-                        else if (y < Y - 1) op = 0;
-                        else op = 1;
-                    } else {
-                        const int tau = x + l, blk = tau >> 4;
-                        if (blk != cw_blk || l != cw_l || c != cw_c) {
-                            cw = t.dir[dir_index<C>(blk, l, c)];
-                            cw_blk = blk; cw_l = l; cw_c = c;
-                        }
-                        const u32 tag = (cw >> ((tau & 15) * 2)) & 3u;
-                        op = (tag == 2u) ? 2 : (tag == 1u ? 0 : 1);
-                    }
-                    if (op == 2) {
-                        if (is_match) {
-                            nm++;
-                            if (!have_last) { have_last = true; la = pos; lb = t.begin_b + x; }
-                            have_first = true; fa = pos; fb = t.begin_b + x;
-                        }
-                        if (want_ops && lane == 0 && len < dt.ops_cap) ops[len] = is_match ? 2 : 3;
-                        x--; pos--;
-                    } else if (op == 1) {  // GAP_B: consumes a
-                        if (want_ops && lane == 0 && len < dt.ops_cap) ops[len] = 1;
-                        y--; pos--;
-                        if (--c < 0) { c = C - 1; l--; }
-                    } else {  // GAP_A: consumes b
-                        if (want_ops && lane == 0 && len < dt.ops_cap) ops[len] = 0;
-                        x--; y++;
-                        if (++c == C) { c = 0; l++; }
-                    }
-                    len++;
-                } else {
-                    // interior: consume a whole run of diagonal steps from one direction word
-                    const int tau = x + l, blk = tau >> 4, r = tau & 15;
-                    if (blk != cw_blk || l != cw_l || c != cw_c) {
-                        cw = t.dir[dir_index<C>(blk, l, c)];
-                        cw_blk = blk; cw_l = l; cw_c = c;
-                    }
-                    const u32 T = (cw ^ 0xAAAAAAAAu) << (30 - 2 * r);  // pair r on top; diag pairs are 00
-                    int n = T ? (__builtin_clz(T) >> 1) : (r + 1);
-                    n = min(n, min(x, pos));  // stay in x >= 1, pos >= 1
-                    if (n > 0) {
-                        const int64_t ia = t.a_base + pos - n + 1, ib = t.b_base + t.begin_b + x - n + 1;
-                        const u32 xr = fetch16(t.a2, ia) ^ fetch16(t.b2, ib);
-                        u32 ne = (xr | (xr >> 1)) & 0x55555555u;  // bit 2k set: bases k differ
-                        if (HASN) {
-                            u32 nn = fetch16n(t.an, ia) | fetch16n(t.bn, ib);  // either is N -> MATCH
-                            // spread 16 bits to even positions
-                            nn = (nn | (nn << 8)) & 0x00FF00FFu;
-                            nn = (nn | (nn << 4)) & 0x0F0F0F0Fu;
-                            nn = (nn | (nn << 2)) & 0x33333333u;
-                            nn = (nn | (nn << 1)) & 0x55555555u;
-                            ne &= ~nn;
-                        }
-                        const u32 msk = (n == 16) ? 0x55555555u : (((1u << (2 * n)) - 1u) & 0x55555555u);
-                        const u32 eq = ~ne & msk;
-                        if (eq) {
-                            nm += (u32)__builtin_popcount(eq);
-                            const int hi = (31 - __builtin_clz(eq)) >> 1, lo = __builtin_ctz(eq) >> 1;
-                            if (!have_last) { have_last = true; la = pos - n + 1 + hi; lb = t.begin_b + x - n + 1 + hi; }
-                            have_first = true; fa = pos - n + 1 + lo; fb = t.begin_b + x - n + 1 + lo;
-                        }
-                        x -= n; pos -= n; len += (u32)n;
-                    } else {
-                        const u32 tag = (cw >> (r * 2)) & 3u;
-                        if (tag == 1u) {  // GAP_A
-                            x--; y++;
-                            if (++c == C) { c = 0; l++; }
-                        } else {  // GAP_B
-                            y--; pos--;
-                            if (--c < 0) { c = C - 1; l--; }
-                        }
-                        len++;
-                    }
-                }
-            }
-            res.begin_a = pos + 1;
-            res.begin_b = t.begin_b + x + 1;
-            res.score = best;
-            res.n_match = nm;
-            res.length = len;
-            // first_match_pos without a MATCH returns the end coordinates, last_match_pos the begin ones
-            res.first_a = have_first ? fa : end_pos + 1;
-            res.first_b = have_first ? fb : t.begin_b + end_x + 1;
-            res.last_a = have_last ? la : res.begin_a;
-            res.last_b = have_last ? lb : res.begin_b;
-            res.flags = (have_first ? 1u : 0u) | (have_last ? 2u : 0u) | (ST_OK << 8);
+            slow_block<C, CE, HASN>(&st, &t, blk, lane);
+            ++blk;
         }
     }
-    if (lane == 0) p.results[dt.res_idx] = res;
-    __syncthreads();
+    finish_task<C, HASN>(&t, &dt, &p, lane);
 }
 
 template <int C, int CE, bool HASN>
