@@ -16,6 +16,11 @@ typedef uint64_t u64;
 // fetches (which run up to band+64*17 bases outside the contig) never leave the allocation.
 constexpr int SEQ_PAD_BASES = 4096;
 
+// resident waves per SIMD the kernels are register-budgeted for (4 SIMDs per CU)
+#ifndef GAMDP_WAVES_PER_SIMD
+#define GAMDP_WAVES_PER_SIMD 5
+#endif
+
 // one find_alignment call, pre-validated and pre-sized on the host
 struct DevTask {
     const u32* a2;  // word holding base 0 of sequence a (2-bit plane)

@@ -331,7 +331,7 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
     hostTasks.reserve(n);
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; };
     std::vector<Launch> launches;
-    const u32 max_resident = (u32)n_cu * 16u;
+    const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(0);
     for (int kid = 0; kid < K_COUNT; kid++) {
         auto& g = groups[kid];
         if (g.empty()) continue;

@@ -165,6 +165,9 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 
         int L = Lin;
         int x = NEG;
+        // (Computing all diag candidates of the row up front, ahead of the max3 chain, removes the s_nops the
+        // compiler pads the dot4 -> VALU hazard with, but measured 3 % slower: the interleaved form below gives
+        // each wave independent work between the dependent max3 -> and -> max3 steps.)
         auto cell = [&](const int c) __attribute__((always_inline)) {
             int D;
             if (HASN) D = Lp[c] + (int)__builtin_amdgcn_perm(bhi, brow, W[r + c]);
@@ -192,7 +195,10 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 
         if (!SLOW || act) cell(0);
         x = wave_shl1(Lp[0]);
-        x = (lane >= LE) ? NEG : x;
+        // The last band column has no `up` source.  When it is the last column of lane LE the value arriving
+        // from lane LE+1 must be dropped; otherwise (tuned kernels with CE < C-1) column C-1 of lane LE lies
+        // outside the band and whatever arrives only feeds dead cells.
+        if (CE < 0 || CE == C - 1) x = (lane >= LE) ? NEG : x;
         if (!SLOW || act) {
 #pragma unroll
             for (int c = 1; c < C; ++c) cell(c);
@@ -320,6 +326,15 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
         an_lo = t.an[ia >> 5]; an_hi = t.an[(ia >> 5) + 1];
         bn_lo = t.bn[ib >> 5]; bn_hi = t.bn[(ib >> 5) + 1];
     }
+    // Make everything loaded so far land BEFORE the loop: otherwise the compiler parks the `s_waitcnt vmcnt(0)`
+    // of these loads inside the loop (at their first use), where it would also drain the direction stores of
+    // the previous block on every iteration.
+    asm volatile("" : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi), "+v"(Lin));
+    if (HASN) asm volatile("" : "+v"(an_lo), "+v"(an_hi), "+v"(bn_lo), "+v"(bn_hi));
+#pragma unroll
+    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(Lp[c]), "+v"(acc[c]));
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k) asm volatile("" : "+v"(W[k]));
     for (int blk = blk_begin; blk < blk_end; ++blk) {
         const int tau0 = blk * ROWS;
         const u32 a_nx = pa[blk + 2], b_nx = pb[blk + 2];  // prefetch for block blk+1
@@ -706,7 +721,7 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
 }
 
 template <int C, int CE, bool HASN>
-__global__ __launch_bounds__(64, 4) void k_align(const LaunchParams p)
+__global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align(const LaunchParams p)
 {
     const int lane = threadIdx.x;
     u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
@@ -733,7 +748,7 @@ int kernel_cols(int kid)
     }
 }
 
-int kernel_waves_per_cu(int) { return 16; }
+int kernel_waves_per_cu(int) { return 4 * GAMDP_WAVES_PER_SIMD; }
 
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
 {

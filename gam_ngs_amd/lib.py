@@ -64,7 +64,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(HERE, "libgamdp.so")
+    # GAMDP_LIB lets experiments (tools/) load an alternative build; the default is the in-tree library
+    return os.environ.get("GAMDP_LIB") or os.path.join(HERE, "libgamdp.so")
 
 
 def load_library():
