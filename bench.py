@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=16384, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=100000,
+                    help="pairs per GPU per step (default: all 100 k pairs of BASELINE config 5)")
     ap.add_argument("--len", type=int, default=50000)
     ap.add_argument("--band", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,19 +96,15 @@ def main():
     ctx = gam.Context(local_rank)
     P, length, band = args.pairs, args.len, args.band
     first = rank * P  # static partition of the pair list: rank r owns pairs [r*P, (r+1)*P)
-    seqs = []
-    for k in range(P):
-        m, s = api.synth_pair(first + k, length)
-        seqs.append(m)
-        seqs.append(s)
-    sset = gam.SequenceSet(ctx, seqs, ascii=False)
+    # pairs are generated + packed inside the library (same generator as gamdp_synth_pair / the oracle) and
+    # uploaded once: sequence 2k = master, 2k+1 = slave of pair first+k
+    sset = gam.SequenceSet.synthetic(ctx, first, P, length)
     tasks = (L.Task * P)()
     for k in range(P):
         t = tasks[k]
         t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, band
-        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, length - 1, 0, len(seqs[2 * k + 1]) - 1
+        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, length - 1, 0, sset.lengths[2 * k + 1] - 1
     out = (L.Result * P)()
-    del seqs
 
     def step():
         rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
@@ -156,7 +153,7 @@ def main():
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
         if not args.no_cpu_baseline:
-            n_cpu = args.cpu_pairs or 8 * min(os.cpu_count() or 1, 16)
+            n_cpu = args.cpu_pairs or 32 * min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(length, band, first, min(n_cpu, P))
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -76,6 +76,20 @@ class SequenceSet:
         self.handle = h
         self.lengths = [len(s) for s in self._keep]
 
+    @classmethod
+    def synthetic(cls, ctx: "Context", first_pair: int, n_pairs: int, length: int):
+        """Pairs [first_pair, first_pair+n_pairs) of the benchmark generator, built and packed inside the
+        library (sequence 2k = master, 2k+1 = slave); no host copy of the bases is kept."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._keep = []
+        h = C.c_void_p()
+        _check(ctx, ctx.lib.gamdp_seqset_create_synth(ctx.handle, first_pair, n_pairs, length, C.byref(h)),
+               "gamdp_seqset_create_synth")
+        self.handle = h
+        self.lengths = [ctx.lib.gamdp_seqset_length(h, i) for i in range(2 * n_pairs)]
+        return self
+
     def __len__(self):
         return len(self.lengths)
 

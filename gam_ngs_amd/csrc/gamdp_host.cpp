@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +64,7 @@ int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, 
 {
     ctx = ctx_;
     codes.resize(n);
+    this->lens.assign(lens, lens + n);
     fwd.resize(n);
     rc.assign(n, DevSeq{nullptr, nullptr});
     has_n.assign(n, 0);
@@ -90,6 +93,80 @@ int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, 
     HIPCHK(ctx, hipMemcpyAsync(dn, hn.data(), hn.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (u32 i = 0; i < n; i++) fwd[i] = DevSeq{d2 + at[i] / 16, dn + at[i] / 32};
+    return 0;
+}
+
+
+// splitmix64 stream of synthetic pair k (same generator as gamdp_synth_pair below)
+namespace {
+struct SynthGen {
+    uint64_t s;
+    explicit SynthGen(uint64_t k) : s(0x47414DULL + k * 0xD1B54A32D192ED03ULL) { (void)next(); }
+    uint64_t next()
+    {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+};
+uint64_t synth_pair_codes(uint64_t k, uint64_t len, uint8_t* master, uint8_t* slave)
+{
+    SynthGen g(k);
+    for (uint64_t i = 0; i < len; i++) master[i] = (uint8_t)(g.next() >> 62);
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < len; i++) {
+        const uint64_t r = g.next(), u = r >> 40;
+        if (u >= 167772) {                       // 1 % deletion below this
+            uint8_t base = master[i];
+            if (u < 671088) base = (uint8_t)((base + 1 + (r & 0xFFFF) % 3) & 3);  // 3 % substitution
+            slave[n++] = base;
+        }
+        const uint64_t r2 = g.next();
+        if ((r2 >> 40) < 167772) slave[n++] = (uint8_t)(r2 & 3);                 // 1 % insertion
+    }
+    return n;
+}
+}  // namespace
+
+// Benchmark helper: generate synthetic pairs [first_pair, first_pair + n_pairs) on host threads straight into the
+// packed planes (sequence 2k = master, 2k+1 = slave) and upload them; no 1 B/base host copy is kept.
+int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint32_t n_pairs, uint64_t len)
+{
+    ctx = ctx_;
+    const u32 n = 2 * n_pairs;
+    lens.assign(n, 0);
+    fwd.resize(n);
+    rc.assign(n, DevSeq{nullptr, nullptr});
+    has_n.assign(n, 0);
+    const u64 stride = padded_bases(len + len / 8 + 64);  // fixed slot per sequence (slave length varies)
+    const u64 total = stride * n;
+    std::vector<u32> h2(total / 16 + 4, 0), hn(total / 32 + 4, 0);
+    const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    std::atomic<u32> cursor(0);
+    for (unsigned t = 0; t < nt; t++) {
+        th.emplace_back([&]() {
+            std::vector<uint8_t> m(len), s(len + len / 8 + 64);
+            for (;;) {
+                const u32 k = cursor.fetch_add(1);
+                if (k >= n_pairs) break;
+                const u64 sl = synth_pair_codes(first_pair + k, len, m.data(), s.data());
+                lens[2 * k] = len;
+                lens[2 * k + 1] = sl;
+                // slots are 64-base aligned and disjoint, so threads never touch the same word
+                pack_into(m.data(), len, false, h2.data(), hn.data(), stride * (2 * k) + SEQ_PAD_BASES);
+                pack_into(s.data(), sl, false, h2.data(), hn.data(), stride * (2 * k + 1) + SEQ_PAD_BASES);
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    HIPCHK(ctx, hipMalloc(&d2, h2.size() * sizeof(u32)));
+    HIPCHK(ctx, hipMalloc(&dn, hn.size() * sizeof(u32)));
+    HIPCHK(ctx, hipMemcpyAsync(d2, h2.data(), h2.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dn, hn.data(), hn.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (u32 i = 0; i < n; i++) fwd[i] = DevSeq{d2 + (stride * i + SEQ_PAD_BASES) / 16, dn + (stride * i + SEQ_PAD_BASES) / 32};
     return 0;
 }
 
@@ -160,6 +237,8 @@ Ctx::~Ctx()
     if (d_results) (void)hipFree(d_results);
     if (d_ops) (void)hipFree(d_ops);
     if (d_cursor) (void)hipFree(d_cursor);
+    if (h_tasks) (void)hipHostFree(h_tasks);
+    if (h_results) (void)hipHostFree(h_results);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -204,7 +283,7 @@ struct Prepared {
 // returns GAMDP_ST_OK when the task has to run on the GPU, otherwise its final status
 static int prepare_task(const ITask& it, Prepared& pr)
 {
-    const u64 alen_full = it.sa->codes[it.a_id].size(), blen_full = it.sb->codes[it.b_id].size();
+    const u64 alen_full = it.sa->lens[it.a_id], blen_full = it.sb->lens[it.b_id];
     if (it.a_off > alen_full || it.b_off > blen_full) return GAMDP_ST_INVALID;
     const u64 alen = alen_full - it.a_off, blen = blen_full - it.b_off;
     const u64 band = it.band;
@@ -284,7 +363,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         };
         for (const ITask& t : tasks) {
             if (t.band > GAMDP_MAX_BAND) { set_error("band " + std::to_string(t.band) + " exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
-            if (t.a_id >= t.sa->codes.size() || t.b_id >= t.sb->codes.size()) { set_error("sequence id out of range"); return GAMDP_EINVAL; }
+            if (t.a_id >= t.sa->lens.size() || t.b_id >= t.sb->lens.size()) { set_error("sequence id out of range"); return GAMDP_EINVAL; }
+            if ((t.a_rc && !t.sa->has_codes()) || (t.b_rc && !t.sb->has_codes())) { set_error("reverse complement requested on a packed-only (synthetic) sequence set"); return GAMDP_EINVAL; }
             if (t.a_rc) add(t.sa, t.a_id);
             if (t.b_rc) add(t.sb, t.b_id);
         }
@@ -327,8 +407,20 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.6);
     }
 
-    std::vector<DevTask> hostTasks;
-    hostTasks.reserve(n);
+    // pinned staging for the task upload and the result download (pageable copies cost ~20 ms per 60 k tasks)
+    if (n > cap_pinned) {
+        if (h_tasks) (void)hipHostFree(h_tasks);
+        if (h_results) (void)hipHostFree(h_results);
+        h_tasks = nullptr; h_results = nullptr; cap_pinned = 0;
+        const u64 want = n + n / 4;
+        if (hipHostMalloc(&h_tasks, want * sizeof(DevTask)) != hipSuccess ||
+            hipHostMalloc(&h_results, want * sizeof(DevResult)) != hipSuccess) {
+            set_error("hipHostMalloc of staging buffers failed");
+            return GAMDP_ENOMEM;
+        }
+        cap_pinned = want;
+    }
+    u64 n_host_tasks = 0;
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; };
     std::vector<Launch> launches;
     const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(0);
@@ -368,10 +460,10 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
                 }
             }
             Launch L;
-            L.kid = kid; L.first = (u32)hostTasks.size(); L.count = (u32)cur.size();
+            L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)cur.size();
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
             L.n_slots = (u32)std::min<u64>(want, fit);
-            for (u32 i : cur) hostTasks.push_back(prep[i].dt);
+            for (u32 i : cur) h_tasks[n_host_tasks++] = prep[i].dt;
             launches.push_back(L);
         }
     }
@@ -392,7 +484,7 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             d_cursor = nullptr;
             HIPCHK(this, hipMalloc(&d_cursor, launches.size() * sizeof(u32)));
         }
-        HIPCHK(this, hipMemcpyAsync(d_tasks, hostTasks.data(), hostTasks.size() * sizeof(DevTask), hipMemcpyHostToDevice, stream));
+        HIPCHK(this, hipMemcpyAsync(d_tasks, h_tasks, n_host_tasks * sizeof(DevTask), hipMemcpyHostToDevice, stream));
         HIPCHK(this, hipMemsetAsync(d_cursor, 0, std::max<size_t>(64, launches.size()) * sizeof(u32), stream));
         while (events.size() < launches.size()) {
             hipEvent_t a, b;
@@ -411,8 +503,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             if (e != 0) { set_error(std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)e)); return GAMDP_EHIP; }
             HIPCHK(this, hipEventRecord(events[li].second, stream));
         }
-        std::vector<DevResult> hres(n);
-        HIPCHK(this, hipMemcpyAsync(hres.data(), d_results, n * sizeof(DevResult), hipMemcpyDeviceToHost, stream));
+        DevResult* hres = h_results;
+        HIPCHK(this, hipMemcpyAsync(hres, d_results, n * sizeof(DevResult), hipMemcpyDeviceToHost, stream));
         std::vector<uint8_t> hops(ops_total);
         if (ops_total) HIPCHK(this, hipMemcpyAsync(hops.data(), d_ops, ops_total, hipMemcpyDeviceToHost, stream));
         HIPCHK(this, hipStreamSynchronize(stream));
@@ -420,7 +512,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
         }
-        for (const DevTask& d : hostTasks) {
+        for (u64 q = 0; q < n_host_tasks; q++) {
+            const DevTask& d = h_tasks[q];
             const u32 i = d.res_idx;
             fill_result(hres[i], prep[i].cells, out[i]);
             if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
@@ -504,12 +597,12 @@ void gamdp_seqset_destroy(gamdp_seqset* set)
     delete s;
 }
 
-uint32_t gamdp_seqset_size(const gamdp_seqset* set) { return set ? (uint32_t)reinterpret_cast<const SeqSet*>(set)->codes.size() : 0; }
+uint32_t gamdp_seqset_size(const gamdp_seqset* set) { return set ? (uint32_t)reinterpret_cast<const SeqSet*>(set)->lens.size() : 0; }
 
 uint64_t gamdp_seqset_length(const gamdp_seqset* set, uint32_t id)
 {
     const SeqSet* s = reinterpret_cast<const SeqSet*>(set);
-    return (s && id < s->codes.size()) ? s->codes[id].size() : 0;
+    return (s && id < s->lens.size()) ? s->lens[id] : 0;
 }
 
 int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seqset* set_b, const gamdp_task* tasks,
@@ -562,27 +655,21 @@ int64_t gamdp_find_hits(const uint8_t* a, uint64_t alen, uint64_t a_start, uint6
 uint64_t gamdp_synth_pair(uint64_t k, uint64_t len, uint8_t* master, uint8_t* slave)
 {
     // splitmix64 stream keyed by k; see SURVEY.md section 8(d) for the workload definition
-    uint64_t s = 0x47414DULL + k * 0xD1B54A32D192ED03ULL;
-    auto next = [&s]() {
-        uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-        return z ^ (z >> 31);
-    };
-    (void)next();
-    for (uint64_t i = 0; i < len; i++) master[i] = (uint8_t)(next() >> 62);
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < len; i++) {
-        const uint64_t r = next(), u = r >> 40;
-        if (u >= 167772) {                       // 1 % deletion below this
-            uint8_t base = master[i];
-            if (u < 671088) base = (uint8_t)((base + 1 + (r & 0xFFFF) % 3) & 3);  // 3 % substitution
-            slave[n++] = base;
-        }
-        const uint64_t r2 = next();
-        if ((r2 >> 40) < 167772) slave[n++] = (uint8_t)(r2 & 3);                 // 1 % insertion
-    }
-    return n;
+    return synth_pair_codes(k, len, master, slave);
+}
+
+int gamdp_seqset_create_synth(gamdp_ctx* ctx, uint64_t first_pair, uint32_t n_pairs, uint64_t len, gamdp_seqset** out)
+{
+    if (!ctx || !out || len == 0 || len >= (1ull << 30) || n_pairs >= (1u << 30)) return GAMDP_EINVAL;
+    *out = nullptr;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (hipSetDevice(c->device) != hipSuccess) return GAMDP_EHIP;
+    SeqSet* s = new (std::nothrow) SeqSet();
+    if (!s) return GAMDP_ENOMEM;
+    const int rc_ = s->upload_synth(c, first_pair, n_pairs, len);
+    if (rc_) { delete s; return rc_; }
+    *out = reinterpret_cast<gamdp_seqset*>(s);
+    return 0;
 }
 
 }  // extern "C"

@@ -24,7 +24,8 @@ struct DevSeq {
 // packed planes resident in HBM.
 struct SeqSet {
     Ctx* ctx = nullptr;
-    std::vector<std::vector<uint8_t>> codes;
+    std::vector<std::vector<uint8_t>> codes;  // empty for packed-only sets (gamdp_seqset_create_synth)
+    std::vector<u64> lens;
     std::vector<uint8_t> has_n;
     std::vector<DevSeq> fwd;
     mutable std::vector<DevSeq> rc;  // reverse complements, uploaded on first use
@@ -33,6 +34,8 @@ struct SeqSet {
 
     int upload(Ctx* ctx, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, bool ascii);
     int ensure_rc(const std::vector<u32>& ids) const;
+    int upload_synth(Ctx* ctx, uint64_t first_pair, uint32_t n_pairs, uint64_t len);
+    bool has_codes() const { return !codes.empty() || lens.empty(); }
     ~SeqSet();
 };
 
@@ -60,6 +63,9 @@ struct Ctx {
     DevResult* d_results = nullptr; u64 cap_results = 0;
     uint8_t* d_ops = nullptr; u64 cap_ops = 0;
     u32* d_cursor = nullptr;
+    DevTask* h_tasks = nullptr;      // pinned staging
+    DevResult* h_results = nullptr;  // pinned staging
+    u64 cap_pinned = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double kernel_ms = 0;
     u64 kernel_launches = 0;

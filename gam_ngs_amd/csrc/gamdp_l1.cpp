@@ -321,12 +321,13 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     for (size_t i = 0; i < n; i++) {
         Machine& m = M[i];
         m.in = &in[i]; m.out = &out[i]; m.ms = ms; m.ss = ss; m.band = band;
-        if (in[i].m_id < 0 || in[i].s_id < 0 || (size_t)in[i].m_id >= ms->codes.size() || (size_t)in[i].s_id >= ss->codes.size()) {
+        if (!ms->has_codes() || !ss->has_codes()) { c->set_error("merge blocks need sequence sets with host codes"); return GAMDP_EINVAL; }
+        if (in[i].m_id < 0 || in[i].s_id < 0 || (size_t)in[i].m_id >= ms->lens.size() || (size_t)in[i].s_id >= ss->lens.size()) {
             c->set_error("merge block " + std::to_string(i) + ": contig id out of range");
             return GAMDP_EINVAL;
         }
-        m.mlen = ms->codes[in[i].m_id].size();
-        m.slen = ss->codes[in[i].s_id].size();
+        m.mlen = ms->lens[in[i].m_id];
+        m.slen = ss->lens[in[i].s_id];
         if (audit) { m.audit = audit + i * (size_t)audit_stride; m.audit_cap = audit_stride; }
         m.init();
     }

@@ -9,7 +9,7 @@ SYMBOLS = [
     "gamdp_ctx_create", "gamdp_ctx_destroy", "gamdp_ctx_set_arena_bytes", "gamdp_last_error", "gamdp_ctx_stream",
     "gamdp_ctx_kernel_time", "gamdp_seqset_create", "gamdp_seqset_destroy", "gamdp_seqset_size",
     "gamdp_seqset_length", "gamdp_align_batch", "gamdp_align_merge_blocks", "gamdp_find_hits", "gamdp_encode",
-    "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair",
+    "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair", "gamdp_seqset_create_synth",
 ]
 
 EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
@@ -109,5 +109,6 @@ def load_library():
     lib.gamdp_revcomp.restype = None
     lib.gamdp_synth_pair.argtypes = [u64, u64, vp, vp]
     lib.gamdp_synth_pair.restype = u64
+    lib.gamdp_seqset_create_synth.argtypes = [vp, u64, u32, u64, C.POINTER(vp)]
     _lib = lib
     return lib

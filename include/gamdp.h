@@ -170,6 +170,11 @@ void gamdp_revcomp(uint8_t* codes, uint64_t n);
  * codes, slave = master with 3 % substitutions, 1 % insertions, 1 % deletions (splitmix64 keyed by
  * k).  slave must hold len + len/8 + 64 codes; returns the slave length. */
 uint64_t gamdp_synth_pair(uint64_t k, uint64_t len, uint8_t* master, uint8_t* slave);
+/* Benchmark helper: a sequence set holding synthetic pairs [first_pair, first_pair+n_pairs) (sequence 2k =
+ * master, 2k+1 = slave of pair first_pair+k), generated on host threads straight into the packed planes.
+ * Such a set keeps no host copy of the bases: reverse-complement views and merge blocks are refused on it. */
+int gamdp_seqset_create_synth(gamdp_ctx* ctx, uint64_t first_pair, uint32_t n_pairs, uint64_t len,
+                              gamdp_seqset** out);
 
 #ifdef __cplusplus
 }

@@ -138,3 +138,19 @@ def test_empty_batch_and_degenerate_sequences():
     for cs, r in zip(cases, run_cases(cases)):
         o, ops = oracle_for(cs)
         assert r.key() == o.key() and r.ops == ops
+
+
+def test_library_generated_synthetic_set_equals_python_uploaded_one():
+    """gamdp_seqset_create_synth (bench path) must hold exactly the sequences gamdp_synth_pair produces."""
+    c = ctx()
+    n, length = 6, 3000
+    lib_set = gam.SequenceSet.synthetic(c, 40, n, length)
+    pairs = [api.synth_pair(40 + k, length) for k in range(n)]
+    py_set = gam.SequenceSet(c, [x for p in pairs for x in p], ascii=False)
+    assert lib_set.lengths == py_set.lengths
+    bsw = gam.BandedSmithWaterman(c, 150)
+    r1 = bsw.find_alignments([(lib_set.contig(2 * k), 0, length - 1, lib_set.contig(2 * k + 1), 0, lib_set.lengths[2 * k + 1] - 1) for k in range(n)], want_ops=True)
+    r2 = bsw.find_alignments([(py_set.contig(2 * k), 0, length - 1, py_set.contig(2 * k + 1), 0, py_set.lengths[2 * k + 1] - 1) for k in range(n)], want_ops=True)
+    assert [(a.key(), a.ops) for a in r1] == [(b.key(), b.ops) for b in r2]
+    with pytest.raises(gam.GamdpError):  # no host copy of the bases -> reverse-complement views are refused
+        bsw.find_alignment(lib_set.contig(0, rc=True), 0, 10, lib_set.contig(1), 0, 10)
