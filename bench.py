@@ -137,6 +137,17 @@ def main():
         avg_launch_s = (kernel_ms / 1e3) / max(1, launches)
         cells_per_launch = cells_rank * args.steps / max(1, launches)
         achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE need their own rocprofv3 passes, so
+        # they are taken from the committed profile of this same workload; null when the workload differs)
+        traffic = traffic_bytes = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            w = tj["workload"]
+            if (w["pairs_per_launch"], w["len"], w["band"]) == (P, length, band) and launches == args.steps:
+                traffic_bytes = tj["hbm_bytes_per_launch"]
+                traffic = traffic_bytes / avg_launch_s / 1e9
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "GCUPS", "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
@@ -148,7 +159,9 @@ def main():
                        "parallelism": "pair list statically partitioned over %d GPU(s), no collective" % world,
                        "failed_pairs": int(bad_all)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_bytes_per_launch": traffic_bytes,
+                         "algorithmic_bytes_per_launch": cells_per_launch * B_ALG,
                          "kernel": "k_align<17,4,false>", "kernel_ms_per_launch": avg_launch_s * 1e3,
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
