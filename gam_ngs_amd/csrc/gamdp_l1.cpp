@@ -12,8 +12,13 @@
 // round collects the next pending DP call of every unfinished merge block into ONE gamdp L0 batch on
 // the GPU, feeds the results back and advances the machines.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -158,7 +163,7 @@ struct Machine {
     }
 
     // the next find_alignment call of this merge block
-    void pending(ITask& t, std::unordered_map<u32, std::vector<uint8_t>>& rc_cache)
+    void pending(ITask& t, std::unordered_map<u32, std::vector<uint8_t>>& rc_cache, std::mutex& rc_mu)
     {
         t = ITask{};
         t.band = band;
@@ -180,6 +185,7 @@ struct Machine {
         const uint8_t* mc = ms->codes[in->m_id].data();
         const uint8_t* sc;
         if (rev) {
+            std::lock_guard<std::mutex> g(rc_mu);  // node-based map: the data pointer stays valid after unlock
             auto it = rc_cache.find((u32)in->s_id);
             if (it == rc_cache.end()) {
                 std::vector<uint8_t> r = ss->codes[in->s_id];
@@ -332,24 +338,49 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         m.init();
     }
     std::unordered_map<u32, std::vector<uint8_t>> rc_cache;
+    std::mutex rc_mu;
+    const size_t n_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     std::vector<ITask> tasks;
     std::vector<size_t> owner;
     std::vector<gamdp_result> res;
+    const bool diag = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto msec = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double t_pending = 0, t_align = 0, t_feed = 0;
+    int rounds = 0;
     for (;;) {
-        tasks.clear();
+        const auto t0 = now();
         owner.clear();
-        for (size_t i = 0; i < n; i++) {
-            if (M[i].phase == Machine::DONE) continue;
-            ITask t;
-            M[i].pending(t, rc_cache);
-            tasks.push_back(t);
-            owner.push_back(i);
+        for (size_t i = 0; i < n; i++)
+            if (M[i].phase != Machine::DONE) owner.push_back(i);
+        if (owner.empty()) break;
+        tasks.assign(owner.size(), ITask{});
+        // building a pending call can involve a findHits over a contig tail: spread over the host cores,
+        // like the reference's worker threads (merge blocks are independent)
+        {
+            const size_t nt = std::min<size_t>(n_threads, (owner.size() + 63) / 64);
+            auto work = [&](size_t tid) {
+                for (size_t q = tid; q < owner.size(); q += nt) M[owner[q]].pending(tasks[q], rc_cache, rc_mu);
+            };
+            if (nt <= 1) work(0);
+            else {
+                std::vector<std::thread> th;
+                for (size_t tid = 0; tid < nt; tid++) th.emplace_back(work, tid);
+                for (auto& t : th) t.join();
+            }
         }
-        if (tasks.empty()) break;
+        const auto t1 = now();
         res.assign(tasks.size(), gamdp_result{});
         const int rc_ = c->align(tasks, res.data(), nullptr);
         if (rc_) return rc_;
+        const auto t2 = now();
         for (size_t q = 0; q < tasks.size(); q++) M[owner[q]].feed(res[q]);
+        const auto t3 = now();
+        t_pending += msec(t0, t1); t_align += msec(t1, t2); t_feed += msec(t2, t3);
+        rounds++;
     }
+    if (diag)
+        std::fprintf(stderr, "gamdp_align_merge_blocks: %zu merge blocks, %d rounds: pending %.1f ms, align %.1f ms, feed %.1f ms\n",
+                     n, rounds, t_pending, t_align, t_feed);
     return 0;
 }
