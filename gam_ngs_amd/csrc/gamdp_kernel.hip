@@ -93,6 +93,58 @@ struct Tk {
 };
 
 
+// ---- per-wave LDS rings of pre-expanded sequence operands (kernels with 17 columns per lane) -------------
+// Every row of every lane needs two operands derived from the sequences: the one-hot byte of the base entering
+// its a-window and the score row of its b base.  Expanding them costs 6 vector instructions per row per lane
+// (20 issue cycles of ~320).  Instead 16 lanes expand the 16 new a and b bases of a block ONCE, one block
+// ahead, into two LDS rings, and every lane fetches its operands with two ds_reads per row: the LDS pipe is
+// otherwise idle, so this takes the work off the vector ALU.
+//   ring A: entry k = one-hot (or v_perm selector) of a[A0 + k], A0 = a_base + begin_a - band; lane l needs
+//           k = tau + 16*(l+1) at row-time tau.  Stored transposed, pos = (k%16)*128 + (k/16)%128, so the 64
+//           lanes of a read (k = k0 + 16*l) hit 64 consecutive dwords (no bank conflict) and the 16 rows of a
+//           block are 16 compile-time offsets from one per-lane address.
+//   ring B: entry k = score row(s) of b[b_base + begin_b + k]; lane l needs k = tau - l.  128 entries + a copy
+//           of the first 16 behind them so that the 16 rows of a block never wrap.
+constexpr int RING_A = 2048;
+constexpr int RING_B = 128;
+__shared__ u32 s_ringA[RING_A];
+__shared__ u32 s_ringB[2 * (RING_B + ROWS)];
+
+template <int C>
+struct UseLds { static constexpr bool value = (C == 17); };
+
+__device__ __forceinline__ int ringA_pos(int k) { return ((k & 15) << 7) | ((k >> 4) & 127); }
+
+template <bool HASN>
+__device__ __forceinline__ u32 enc_a(u32 code2, bool isn)
+{
+    if (HASN) return 0x0C0C0C00u | (isn ? 4u : code2);  // v_perm selector: byte0 = table[code]
+    return 1u << (code2 * 8u);                          // one-hot byte per base
+}
+template <bool HASN>
+__device__ __forceinline__ void enc_b(u32 code2, bool isn, u32& brow, u32& bhi)
+{
+    // table entry(a) = 4*(S(a,b)+16)+2 : match 86, N-vs-base 66, mismatch 50; bhi = entry for a == N
+    if (HASN && isn) { brow = 0x42424242u; bhi = 0x56u; }
+    else { brow = 0x32323232u + (0x24u << (code2 * 8u)); bhi = 0x42u; }
+}
+
+// lanes 0..15 expand the 16 new entries of the block whose first row-time is T
+template <int C, bool HASN>
+__device__ __forceinline__ void ring_produce(const int T, const int lane, const u32 aw, const u32 anw, const u32 bw, const u32 bnw)
+{
+    if (lane < ROWS) {
+        const int kA = T + (C - 1) * 64 + lane;
+        s_ringA[ringA_pos(kA)] = enc_a<HASN>((aw >> (2 * lane)) & 3u, HASN && ((anw >> lane) & 1u));
+        u32 brow, bhi;
+        enc_b<HASN>((bw >> (2 * lane)) & 3u, HASN && ((bnw >> lane) & 1u), brow, bhi);
+        const int pb = (T + lane) & (RING_B - 1);
+        s_ringB[2 * pb] = brow;
+        s_ringB[2 * pb + 1] = bhi;
+        if (pb < ROWS) { s_ringB[2 * (pb + RING_B)] = brow; s_ringB[2 * (pb + RING_B) + 1] = bhi; }
+    }
+}
+
 // Out-of-line device functions receive their arguments in vector registers, so the compiler has to assume
 // they differ per lane.  Everything in Tk is wave-uniform: re-assert that (v_readfirstlane) once per call so
 // that the callee computes addresses, loop counters and the whole traceback walk on the scalar unit.
@@ -135,20 +187,25 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 {
     const int tau0 = blk * ROWS;
 
+    // LDS operand path: one per-lane address per ring and block, the 16 rows are immediate offsets
+    const u32* ringA_lane = nullptr;
+    const u32* ringB_lane = nullptr;
+    if (UseLds<C>::value) {
+        ringA_lane = s_ringA + (((tau0 >> 4) + lane + 1) & 127);            // k = tau0 + r + 16*(lane+1)
+        ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));          // k = tau0 + r - lane
+    }
+
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        u32 ca = (abits >> (2 * r)) & 3u;
-        u32 cb = (bbits >> (2 * r)) & 3u;
         u32 brow, bhi = 0;
-        if (HASN) {
-            if ((anb >> r) & 1u) ca = 4;
-            W[C - 1 + r] = 0x0C0C0C00u | ca;  // v_perm selector: byte0 = table[ca]
-            const bool bN = (bnb >> r) & 1u;
-            brow = bN ? 0x42424242u : (0x32323232u + (0x24u << (cb * 8u)));
-            bhi = bN ? 0x56u : 0x42u;
+        if (UseLds<C>::value) {
+            W[C - 1 + r] = ringA_lane[r * 128];
+            brow = ringB_lane[2 * r];
+            if (HASN) bhi = ringB_lane[2 * r + 1];
         } else {
-            W[C - 1 + r] = 1u << (ca * 8u);  // one-hot byte per base
-            brow = 0x32323232u + (0x24u << (cb * 8u));
+            const u32 ca = (abits >> (2 * r)) & 3u, cb = (bbits >> (2 * r)) & 3u;
+            W[C - 1 + r] = enc_a<HASN>(ca, HASN && ((anb >> r) & 1u));
+            enc_b<HASN>(cb, HASN && ((bnb >> r) & 1u), brow, bhi);
         }
 
         // slow-path per-row values
@@ -291,10 +348,19 @@ __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const i
     u32 W[C + 15];
     int Lin;
     load_state<C>(st, Lp, acc, W, Lin);
-    const int64_t sA = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1) + blk * ROWS;
-    const int64_t sB = t.b_base + t.begin_b - lane + blk * ROWS;
-    const u32 abits = fetch16(t.a2, sA), bbits = fetch16(t.b2, sB);
-    const u32 anb = HASN ? fetch16n(t.an, sA) : 0u, bnb = HASN ? fetch16n(t.bn, sB) : 0u;
+    u32 abits = 0, bbits = 0, anb = 0, bnb = 0;
+    if (UseLds<C>::value) {
+        // operands of this block are already in the LDS rings; expand the next block's 16 new bases
+        const int T = (blk + 1) * ROWS;
+        const int64_t ia = t.a_base + t.begin_a - t.band + T + (C - 1) * 64, ib = t.b_base + t.begin_b + T;
+        ring_produce<C, HASN>(T, lane, fetch16(t.a2, ia), HASN ? fetch16n(t.an, ia) : 0u, fetch16(t.b2, ib),
+                              HASN ? fetch16n(t.bn, ib) : 0u);
+    } else {
+        const int64_t sA = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1) + blk * ROWS;
+        const int64_t sB = t.b_base + t.begin_b - lane + blk * ROWS;
+        abits = fetch16(t.a2, sA); bbits = fetch16(t.b2, sB);
+        if (HASN) { anb = fetch16n(t.an, sA); bnb = fetch16n(t.bn, sB); }
+    }
     do_block<C, CE, HASN, true>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
     store_state<C>(st, Lp, acc, W, Lin);
 }
@@ -312,6 +378,48 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
     u32 W[C + 15];
     int Lin;
     load_state<C>(st, Lp, acc, W, Lin);
+    if (UseLds<C>::value) {
+        // LDS operand path.  Invariant: on entry of block T the rings hold everything block T reads; the top of
+        // block T expands the 16 new bases of block T+16 from packed words that were requested one block earlier.
+        const int64_t iA0 = t.a_base + t.begin_a - t.band + (C - 1) * 64, iB0 = t.b_base + t.begin_b;
+        gcptr pa = t.a2 + (iA0 >> 4), pb = t.b2 + (iB0 >> 4);  // wave-uniform streams, one word per block
+        const u32 sha = (u32)(iA0 & 15) * 2u, shb = (u32)(iB0 & 15) * 2u;
+        u32 a_lo = pa[blk_begin + 1], a_hi = pa[blk_begin + 2], b_lo = pb[blk_begin + 1], b_hi = pb[blk_begin + 2];
+        u32 an_lo = 0, an_hi = 0, bn_lo = 0, bn_hi = 0;
+        if (HASN) {
+            const int64_t ia = iA0 + (int64_t)(blk_begin + 1) * ROWS, ib = iB0 + (int64_t)(blk_begin + 1) * ROWS;
+            an_lo = t.an[ia >> 5]; an_hi = t.an[(ia >> 5) + 1];
+            bn_lo = t.bn[ib >> 5]; bn_hi = t.bn[(ib >> 5) + 1];
+        }
+        asm volatile("" : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi), "+v"(Lin));
+        if (HASN) asm volatile("" : "+v"(an_lo), "+v"(an_hi), "+v"(bn_lo), "+v"(bn_hi));
+#pragma unroll
+        for (int c = 0; c < C; ++c) asm volatile("" : "+v"(Lp[c]), "+v"(acc[c]));
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) asm volatile("" : "+v"(W[k]));
+        for (int blk = blk_begin; blk < blk_end; ++blk) {
+            const int T = (blk + 1) * ROWS;
+            const u32 a_nx = pa[blk + 3], b_nx = pb[blk + 3];  // words of block blk+2, used at the next iteration
+            u32 an_lo_nx = 0, an_hi_nx = 0, bn_lo_nx = 0, bn_hi_nx = 0;
+            if (HASN) {
+                const int64_t ia = iA0 + T + ROWS, ib = iB0 + T + ROWS;
+                an_lo_nx = t.an[ia >> 5]; an_hi_nx = t.an[(ia >> 5) + 1];
+                bn_lo_nx = t.bn[ib >> 5]; bn_hi_nx = t.bn[(ib >> 5) + 1];
+            }
+            u32 anw = 0, bnw = 0;
+            if (HASN) {
+                anw = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((iA0 + T) & 31)) & 0xFFFFu;
+                bnw = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((iB0 + T) & 31)) & 0xFFFFu;
+            }
+            ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
+                                  __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
+            do_block<C, CE, HASN, false>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, 0u, 0u, 0u, 0u);
+            a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
+            if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
+        }
+        store_state<C>(st, Lp, acc, W, Lin);
+        return;
+    }
     // Per-lane sequence streams advance exactly 16 bases (= one 2-bit word) per block, so each block needs one
     // new word per stream; it is requested one block ahead and only waited for at the top of the next block.
     const int64_t sA0 = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1);  // base index of block 0
@@ -668,6 +776,23 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
         for (int k = C - 1; k < C + 15; ++k) W[k] = 0;
     }
 
+    if (UseLds<C>::value) {
+        // everything block 0 reads: ring A entries k < 16 + 64*(C-1), ring B entries k < 16
+        const int64_t A0 = t.a_base + t.begin_a - w, BB = t.b_base + t.begin_b;
+        for (int k = lane; k < ROWS + (C - 1) * 64; k += 64) {
+            const int64_t ia = A0 + k;
+            const u32 code = (t.a2[ia >> 4] >> ((ia & 15) * 2)) & 3u;
+            const bool isn = HASN && ((t.an[ia >> 5] >> (ia & 31)) & 1u);
+            s_ringA[ringA_pos(k)] = enc_a<HASN>(code, isn);
+        }
+        if (lane < ROWS) {
+            const int64_t ib = BB + lane;
+            u32 brow, bhi;
+            enc_b<HASN>((t.b2[ib >> 4] >> ((ib & 15) * 2)) & 3u, HASN && ((t.bn[ib >> 5] >> (ib & 31)) & 1u), brow, bhi);
+            s_ringB[2 * lane] = brow; s_ringB[2 * lane + 1] = bhi;
+            s_ringB[2 * (lane + RING_B)] = brow; s_ringB[2 * (lane + RING_B) + 1] = bhi;
+        }
+    }
     store_state<C>(st, Lp, acc, W, Lin);
 }
 
