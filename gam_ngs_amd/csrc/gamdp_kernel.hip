@@ -105,15 +105,39 @@ struct Tk {
 //           block are 16 compile-time offsets from one per-lane address.
 //   ring B: entry k = score row(s) of b[b_base + begin_b + k]; lane l needs k = tau - l.  128 entries + a copy
 //           of the first 16 behind them so that the 16 rows of a block never wrap.
+//   (Kernels with fewer columns per lane -- lane stride C-1 not a multiple of 16 -- use the same rings with a
+//   plain layout pos = k % size plus a 16-entry copy behind the ring; their ring-A reads are 2..8-way bank
+//   conflicted, which the otherwise idle LDS pipe absorbs.)
 constexpr int RING_A = 2048;
 constexpr int RING_B = 128;
-__shared__ u32 s_ringA[RING_A];
+__shared__ u32 s_ringA[RING_A + ROWS];
 __shared__ u32 s_ringB[2 * (RING_B + ROWS)];
 
 template <int C>
-struct UseLds { static constexpr bool value = (C == 17); };
+struct UseLds { static constexpr bool value = true; };
 
-__device__ __forceinline__ int ringA_pos(int k) { return ((k & 15) << 7) | ((k >> 4) & 127); }
+// ring A geometry per column count: size = power of two >= 64*(C-1) + 32
+template <int C>
+struct RingA {
+    static constexpr bool transposed = ((C - 1) % 16 == 0);
+    static constexpr int span = 64 * (C - 1) + 32;
+    static constexpr int size = span <= 128 ? 128 : span <= 256 ? 256 : span <= 512 ? 512 : span <= 1024 ? 1024 : 2048;
+    static_assert(span <= RING_A, "ring A too small");
+    // position of entry k
+    static __device__ __forceinline__ int pos(int k)
+    {
+        if (transposed) return ((k & 15) * (size / 16)) | ((k >> 4) & (size / 16 - 1));
+        return k & (size - 1);
+    }
+    // write entry k (plain layout keeps a copy of the first 16 entries behind the ring so that the 16 rows of a
+    // block can be read at immediate offsets without wrapping)
+    static __device__ __forceinline__ void put(int k, u32 v)
+    {
+        const int p = pos(k);
+        s_ringA[p] = v;
+        if (!transposed && p < ROWS) s_ringA[p + size] = v;
+    }
+};
 
 template <bool HASN>
 __device__ __forceinline__ u32 enc_a(u32 code2, bool isn)
@@ -135,7 +159,7 @@ __device__ __forceinline__ void ring_produce(const int T, const int lane, const 
 {
     if (lane < ROWS) {
         const int kA = T + (C - 1) * 64 + lane;
-        s_ringA[ringA_pos(kA)] = enc_a<HASN>((aw >> (2 * lane)) & 3u, HASN && ((anw >> lane) & 1u));
+        RingA<C>::put(kA, enc_a<HASN>((aw >> (2 * lane)) & 3u, HASN && ((anw >> lane) & 1u)));
         u32 brow, bhi;
         enc_b<HASN>((bw >> (2 * lane)) & 3u, HASN && ((bnw >> lane) & 1u), brow, bhi);
         const int pb = (T + lane) & (RING_B - 1);
@@ -191,7 +215,9 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     const u32* ringA_lane = nullptr;
     const u32* ringB_lane = nullptr;
     if (UseLds<C>::value) {
-        ringA_lane = s_ringA + (((tau0 >> 4) + lane + 1) & 127);            // k = tau0 + r + 16*(lane+1)
+        // k = tau0 + r + (C-1)*(lane+1)
+        if (RingA<C>::transposed) ringA_lane = s_ringA + (((tau0 + (C - 1) * (lane + 1)) >> 4) & (RingA<C>::size / 16 - 1));
+        else ringA_lane = s_ringA + ((tau0 + (C - 1) * (lane + 1)) & (RingA<C>::size - 1));
         ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));          // k = tau0 + r - lane
     }
 
@@ -199,7 +225,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     for (int r = 0; r < ROWS; ++r) {
         u32 brow, bhi = 0;
         if (UseLds<C>::value) {
-            W[C - 1 + r] = ringA_lane[r * 128];
+            W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * (RingA<C>::size / 16) : r];
             brow = ringB_lane[2 * r];
             if (HASN) bhi = ringB_lane[2 * r + 1];
         } else {
@@ -783,7 +809,7 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
             const int64_t ia = A0 + k;
             const u32 code = (t.a2[ia >> 4] >> ((ia & 15) * 2)) & 3u;
             const bool isn = HASN && ((t.an[ia >> 5] >> (ia & 31)) & 1u);
-            s_ringA[ringA_pos(k)] = enc_a<HASN>(code, isn);
+            RingA<C>::put(k, enc_a<HASN>(code, isn));
         }
         if (lane < ROWS) {
             const int64_t ib = BB + lane;
