@@ -83,11 +83,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # BENCH_SHARE_GPU=1 (testing only): all ranks use GPU 0 and talk over gloo, to exercise the N>1 code path on
+    # a single-GPU box; the reported number is then NOT a multi-GPU measurement.
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo" if share_gpu else "nccl")
     torch.cuda.set_device(local_rank)
 
     import gam_ngs_amd as gam
@@ -117,6 +122,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -132,7 +139,8 @@ def main():
     cells_rank = sum(out[k].cells for k in range(P))
     bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
     from gam_ngs_amd import shard
-    dt_max, cells_all, bad_all = shard.reduce_step_stats(dt, float(cells_rank), float(bad), device="cuda")
+    dt_max, cells_all, bad_all = shard.reduce_step_stats(dt, float(cells_rank), float(bad),
+                                                         device="cpu" if share_gpu else "cuda")
 
     if rank == 0:
         gcups = cells_all * args.steps / dt_max / 1e9
