@@ -70,13 +70,15 @@ __device__ __forceinline__ int code_at(gcptr p2, gcptr pn, int64_t idx)
 }
 __device__ __forceinline__ int score_of(int p, int q) { return p == q ? 5 : ((p == 4 || q == 4) ? 0 : -4); }
 
-__device__ __forceinline__ int wave_shl1(int v)  // lane l <- lane l+1 ; lane 63 <- NEG
+// DPP wave shifts.  The lane without a source keeps `keep` (pass the previous result: it was NEG at the start of
+// the task and so stays NEG, without a v_mov to re-materialise the constant before every shift).
+__device__ __forceinline__ int wave_shl1(int keep, int v)  // lane l <- lane l+1 ; lane 63 <- keep
 {
-    return __builtin_amdgcn_update_dpp(NEG, v, 0x130, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(keep, v, 0x130, 0xf, 0xf, false);
 }
-__device__ __forceinline__ int wave_shr1(int v)  // lane l <- lane l-1 ; lane 0 <- NEG
+__device__ __forceinline__ int wave_shr1(int keep, int v)  // lane l <- lane l-1 ; lane 0 <- keep
 {
-    return __builtin_amdgcn_update_dpp(NEG, v, 0x138, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(keep, v, 0x138, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
 
@@ -221,6 +223,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
         ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));          // k = tau0 + r - lane
     }
 
+    int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         u32 brow, bhi = 0;
@@ -247,7 +250,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
         }
 
         int L = Lin;
-        int x = NEG;
+        int x;
         // (Computing all diag candidates of the row up front, ahead of the max3 chain, removes the s_nops the
         // compiler pads the dot4 -> VALU hazard with, but measured 3 % slower: the interleaved form below gives
         // each wave independent work between the dependent max3 -> and -> max3 steps.)
@@ -277,7 +280,8 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
         };
 
         if (!SLOW || act) cell(0);
-        x = wave_shl1(Lp[0]);
+        x = wave_shl1(xkeep, Lp[0]);
+        xkeep = x;
         // The last band column has no `up` source.  When it is the last column of lane LE the value arriving
         // from lane LE+1 must be dropped; otherwise (tuned kernels with CE < C-1) column C-1 of lane LE lies
         // outside the band and whatever arrives only feeds dead cells.
@@ -286,7 +290,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 #pragma unroll
             for (int c = 1; c < C; ++c) cell(c);
         }
-        Lin = wave_shr1(L);
+        Lin = wave_shr1(Lin, L);
 
         if (SLOW) {
             if (act && row <= t.X - 1) {
