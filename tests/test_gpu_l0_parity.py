@@ -154,3 +154,22 @@ def test_library_generated_synthetic_set_equals_python_uploaded_one():
     assert [(a.key(), a.ops) for a in r1] == [(b.key(), b.ops) for b in r2]
     with pytest.raises(gam.GamdpError):  # no host copy of the bases -> reverse-complement views are refused
         bsw.find_alignment(lib_set.contig(0, rc=True), 0, 10, lib_set.contig(1), 0, 10)
+
+
+def test_row_cap_and_long_tasks_against_oracle():
+    """BSW_MAX_ALIGNMENT: the reference fills at most 500 000 rows (banded_smith_waterman.cc:95).  A 520 kb pair at
+    band 5 must stop there, bit for bit like the oracle; plus a 120 kb pair at the live band 150 (7 500 blocks)."""
+    import _cases
+    rng = random.Random(2)
+    a, b = _cases.related_pair(rng, 520000, div=0.6)
+    a2, b2 = _cases.related_pair(rng, 120000, n_frac=0.001)
+    cases = [dict(a=a.encode(), b=b.encode(), band=5, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False),
+             dict(a=a2.encode(), b=b2.encode(), band=150, begin_a=0, end_a=len(a2) - 1, begin_b=0, end_b=len(b2) - 1, fs=False, fe=False)]
+    for want_ops in (False, True):
+        res = run_cases(cases, want_ops=want_ops)
+        for cs, r in zip(cases, res):
+            o, ops = oracle_for(cs, want_ops)
+            assert r.key() == o.key(), (cs["band"], r.key(), o.key())
+            if want_ops:
+                assert r.ops == ops
+    assert res[0].cells == 500000 * 11
