@@ -114,6 +114,7 @@ constexpr int RING_A = 2048;
 constexpr int RING_B = 128;
 __shared__ u32 s_ringA[RING_A + ROWS];
 __shared__ u32 s_ringB[2 * (RING_B + ROWS)];
+__shared__ int s_cap[2][2][20];  // side-capture scratch [pos==0 | pos==end_a][lane parity], see do_block
 
 template <int C>
 struct UseLds { static constexpr bool value = true; };
@@ -206,8 +207,12 @@ __device__ __forceinline__ u64 dir_index(int blk, int lane, int c)
 }
 
 // ---- one block of 16 row-times --------------------------------------------------------------------
-template <int C, int CE, bool HASN, bool SLOW>
-__device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, const Tk& t,
+// MODE bit 0 (TOP): lanes may still be before row 1, cells with pos <= 0 exist (the reference's pos==0 rules).
+// MODE bit 1 (END): rows of the pos==end_a anti-diagonal and/or the last row are in the block (side captures).
+enum { M_FAST = 0, M_TOP = 1, M_END = 2, M_BOTH = 3 };
+
+template <int C, int CE, bool HASN, int MODE>
+__device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t,
                                          const int blk, const int lane, const int LE, const int kill_c,
                                          const u32 abits, const u32 bbits, const u32 anb, const u32 bnb)
 {
@@ -237,14 +242,15 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
             enc_b<HASN>(cb, HASN && ((bnb >> r) & 1u), brow, bhi);
         }
 
-        // slow-path per-row values
+        // per-row values of the special modes
+        constexpr bool TOP = (MODE & M_TOP) != 0, END = (MODE & M_END) != 0;
         const int row = tau0 + r - lane;
-        bool act = true;
-        int cm1 = 0, cE = 0, Zst = 0, ZL = 0, cap0 = 0, capE = 0;
-        if (SLOW) {
-            act = row >= 1;
+        bool act = true;  // lanes before their row 1 (TOP) or past their last row (END) sit the row out
+        int cm1 = 0, Zst = 0, ZL = 0;
+        if (END) act = row <= t.X - 1;
+        if (TOP) {
+            act = act && row >= 1;
             cm1 = (t.band - t.begin_a - row - 1) - C * lane;  // column whose pos == -1
-            cE = (t.eaRel - row) - C * lane;                  // column whose pos == end_a
             Zst = 32 * row + 32 * (t.band - t.begin_a - 1);   // G4 of H = 0 at the pos == -1 cell
             ZL = (t.fs && row > FORCE_MAXGAP) ? NEG : Zst;    // ... as a `left` source (:150-155)
         }
@@ -267,10 +273,8 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
             const int R = imax3(D, Uc, L);
             acc[c] = __builtin_amdgcn_alignbit((u32)R, acc[c], 2);
             const int Lc = R & ~3;
-            if (SLOW) {
-                const bool m1 = (cm1 == c);
-                cap0 = (cm1 == c - 1) ? R : cap0;
-                capE = (cE == c) ? R : capE;
+            if (TOP) {
+                const bool m1 = (cm1 == c);  // the pos == -1 cell holds H = 0 (the reference's zero-initialised matrix)
                 Lp[c] = m1 ? Zst : Lc;
                 L = m1 ? ZL : Lc;
             } else {
@@ -279,38 +283,58 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
             }
         };
 
-        if (!SLOW || act) cell(0);
+        if (MODE == M_FAST || act) cell(0);
         x = wave_shl1(xkeep, Lp[0]);
         xkeep = x;
         // The last band column has no `up` source.  When it is the last column of lane LE the value arriving
         // from lane LE+1 must be dropped; otherwise (tuned kernels with CE < C-1) column C-1 of lane LE lies
         // outside the band and whatever arrives only feeds dead cells.
         if (CE < 0 || CE == C - 1) x = (lane >= LE) ? NEG : x;
-        if (!SLOW || act) {
+        if (MODE == M_FAST || act) {
 #pragma unroll
             for (int c = 1; c < C; ++c) cell(c);
+            Lout = L;
         }
-        Lin = wave_shr1(Lin, L);
+        // a lane that sits the row out hands over its last real chain value (its right neighbour is one row behind)
+        Lin = wave_shr1(Lin, (MODE == M_FAST) ? L : Lout);
 
-        if (SLOW) {
-            if (act && row <= t.X - 1) {
-                const int c0 = cm1 + 1;
-                if (c0 >= 0 && c0 < C) {
-                    const int j0 = C * lane + c0;
-                    if (j0 < t.Y) t.pos0[row] = (cap0 >> 2) - 16 * row - 8 * j0;
-                }
-                if (cE >= 0 && cE < C) {
-                    const int jE = C * lane + cE;
-                    if (jE < t.Y) t.adh[row - t.iA] = (capE >> 2) - 16 * row - 8 * jE;
-                }
-                if (row == t.X - 1) {
+        // Side captures.  Every lane works on its own row, and the column of that row's pos==0 (pos==end_a) cell
+        // moves by C-1 from lane to lane, so at any row-time at most two ADJACENT lanes hold such a cell.  Those
+        // lanes drop their row values into a tiny LDS buffer (one per lane parity) and pick the one they need by
+        // index (a dynamic register index would cost a compare + select per cell for every lane).
+        if (TOP) {
+            const int c0 = cm1 + 1;  // column of the pos == 0 cell
+            if (act && row <= t.X - 1 && c0 >= 0 && c0 < C) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const int j = C * lane + c;
-                        if (j < t.Y) t.lastrow[j] = (Lp[c] >> 2) - 16 * row - 8 * j;
-                    }
-                }
+                for (int c = 0; c < C; ++c) s_cap[0][lane & 1][c] = Lp[c];
+                const int j0 = C * lane + c0;
+                if (j0 < t.Y) t.pos0[row] = (s_cap[0][lane & 1][c0] >> 2) - 16 * row - 8 * j0;
             }
+        }
+        if (END) {
+            const int cE = (t.eaRel - row) - C * lane;  // column whose pos == end_a
+            if (row >= 1 && row <= t.X - 1 && cE >= 0 && cE < C) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) s_cap[1][lane & 1][c] = Lp[c];
+                const int jE = C * lane + cE;
+                if (jE < t.Y) t.adh[row - t.iA] = (s_cap[1][lane & 1][cE] >> 2) - 16 * row - 8 * jE;
+            }
+        }
+    }
+    if (MODE & M_END) {
+        // lanes stopped updating after their last row, so the registers still hold row X-1 when it fell in this block
+        const int rX = t.X - 1 - (tau0 - lane);  // position of the lane's last row in this block
+        if (t.X > 1 && rX >= 0 && rX < ROWS) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int j = C * lane + c;
+                if (j < t.Y) t.lastrow[j] = (Lp[c] >> 2) - 16 * (t.X - 1) - 8 * j;
+            }
+            // the direction words were shifted in from the top one row at a time: a lane that stopped at row rX
+            // has its rows 2*(15-rX) bits too high
+            const u32 sh = 2u * (u32)(ROWS - 1 - rX);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] >>= sh;
         }
     }
 
@@ -337,6 +361,7 @@ struct BlockState {
     u32 acc[C];
     u32 W[C + 15];
     int Lin;
+    int Lout;  // last chain value of the lane's last column (what it hands to its right neighbour)
 };
 
 // The fill is driven through three out-of-line functions that hand the per-lane register state over in a
@@ -346,7 +371,7 @@ struct BlockState {
 // register allocation: nothing live in the other phases can force a spill (and with it a full
 // `s_waitcnt vmcnt(0)` drain of the outstanding direction stores) into it.
 template <int C>
-__device__ __forceinline__ void load_state(const BlockState<C>* st, int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin)
+__device__ __forceinline__ void load_state(const BlockState<C>* st, int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, int& Lout)
 {
 #pragma unroll
     for (int c = 0; c < C; ++c) { Lp[c] = st->Lp[c]; acc[c] = st->acc[c]; }
@@ -355,18 +380,20 @@ __device__ __forceinline__ void load_state(const BlockState<C>* st, int (&Lp)[C]
 #pragma unroll
     for (int k = C - 1; k < C + 15; ++k) W[k] = 0;
     Lin = st->Lin;
+    Lout = st->Lout;
 }
 template <int C>
-__device__ __forceinline__ void store_state(BlockState<C>* st, const int (&Lp)[C], const u32 (&acc)[C], const u32 (&W)[C + 15], const int Lin)
+__device__ __forceinline__ void store_state(BlockState<C>* st, const int (&Lp)[C], const u32 (&acc)[C], const u32 (&W)[C + 15], const int Lin, const int Lout)
 {
 #pragma unroll
     for (int c = 0; c < C; ++c) { st->Lp[c] = Lp[c]; st->acc[c] = acc[c]; }
 #pragma unroll
     for (int k = 0; k < C - 1; ++k) st->W[k] = W[k];
     st->Lin = Lin;
+    st->Lout = Lout;
 }
 
-template <int C, int CE, bool HASN>
+template <int C, int CE, bool HASN, int MODE>
 __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const int blk_, const int lane)
 {
     const Tk t = load_uniform(tp);
@@ -376,8 +403,8 @@ __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const i
     int Lp[C];
     u32 acc[C];
     u32 W[C + 15];
-    int Lin;
-    load_state<C>(st, Lp, acc, W, Lin);
+    int Lin, Lout;
+    load_state<C>(st, Lp, acc, W, Lin, Lout);
     u32 abits = 0, bbits = 0, anb = 0, bnb = 0;
     if (UseLds<C>::value) {
         // operands of this block are already in the LDS rings; expand the next block's 16 new bases
@@ -391,8 +418,8 @@ __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const i
         abits = fetch16(t.a2, sA); bbits = fetch16(t.b2, sB);
         if (HASN) { anb = fetch16n(t.an, sA); bnb = fetch16n(t.bn, sB); }
     }
-    do_block<C, CE, HASN, true>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
-    store_state<C>(st, Lp, acc, W, Lin);
+    do_block<C, CE, HASN, MODE>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
+    store_state<C>(st, Lp, acc, W, Lin, Lout);
 }
 
 // blocks [blk_begin, blk_end) are all "fast": every lane is past row 0, no pos <= 0 cell, no capture row
@@ -406,8 +433,8 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
     int Lp[C];
     u32 acc[C];
     u32 W[C + 15];
-    int Lin;
-    load_state<C>(st, Lp, acc, W, Lin);
+    int Lin, Lout;
+    load_state<C>(st, Lp, acc, W, Lin, Lout);
     if (UseLds<C>::value) {
         // LDS operand path.  Invariant: on entry of block T the rings hold everything block T reads; the top of
         // block T expands the 16 new bases of block T+16 from packed words that were requested one block earlier.
@@ -443,11 +470,11 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
             }
             ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
                                   __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
-            do_block<C, CE, HASN, false>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, 0u, 0u, 0u, 0u);
+            do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c, 0u, 0u, 0u, 0u);
             a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
             if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
         }
-        store_state<C>(st, Lp, acc, W, Lin);
+        store_state<C>(st, Lp, acc, W, Lin, Lout);
         return;
     }
     // Per-lane sequence streams advance exactly 16 bases (= one 2-bit word) per block, so each block needs one
@@ -489,11 +516,11 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
             anb = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((sA0 + tau0) & 31)) & 0xFFFFu;
             bnb = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((sB0 + tau0) & 31)) & 0xFFFFu;
         }
-        do_block<C, CE, HASN, false>(Lp, acc, W, Lin, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
+        do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
         a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
         if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
     }
-    store_state<C>(st, Lp, acc, W, Lin);
+    store_state<C>(st, Lp, acc, W, Lin, Lout);
 }
 
 // ---- phases C + D: end-cell search and traceback ------------------------------------------------------
@@ -748,7 +775,7 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
     int Lp[C];
     u32 acc[C];
     u32 W[C + 15];
-    int Lin = NEG;
+    int Lin = NEG, Lout = NEG;
     {
         const int cb0 = code_at(t.b2, t.bn, t.b_base + t.begin_b);
         int e[C];
@@ -823,7 +850,7 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
             s_ringB[2 * (lane + RING_B)] = brow; s_ringB[2 * (lane + RING_B) + 1] = bhi;
         }
     }
-    store_state<C>(st, Lp, acc, W, Lin);
+    store_state<C>(st, Lp, acc, W, Lin, Lout);
 }
 
 // ---- the whole task -------------------------------------------------------------------------------
@@ -856,19 +883,23 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
     // ---- phase B: rows 1..X-1 in blocks of 16 row-times ----------------------------------------------------
     const int nblk = (X - 1 + LE) / ROWS + 1;
     const int64_t iE0 = t.end_a - t.begin_a - w, iE1 = t.end_a - t.begin_a + w;
-    auto is_fast = [&](const int blk) {
+    auto mode_of = [&](const int blk) {
         const int tau0 = blk * ROWS;
-        return (tau0 - LE >= 1) && (t.begin_a - w + tau0 >= 1) && (tau0 + ROWS - 1 < X - 1) &&
-               ((int64_t)(tau0 + ROWS - 1) < iE0 || (int64_t)(tau0 - LE) > iE1);
+        const bool top = !((tau0 - LE >= 1) && (t.begin_a - w + tau0 >= 1));
+        const bool end = !((tau0 + ROWS - 1 < X - 1) && ((int64_t)(tau0 + ROWS - 1) < iE0 || (int64_t)(tau0 - LE) > iE1));
+        return (top ? M_TOP : 0) | (end ? M_END : 0);
     };
     for (int blk = 0; blk < nblk;) {
-        if (is_fast(blk)) {
+        const int m = mode_of(blk);
+        if (m == M_FAST) {
             int e = blk + 1;
-            while (e < nblk && is_fast(e)) ++e;
+            while (e < nblk && mode_of(e) == M_FAST) ++e;
             fast_range<C, CE, HASN>(&st, &t, blk, e, lane);
             blk = e;
         } else {
-            slow_block<C, CE, HASN>(&st, &t, blk, lane);
+            if (m == M_TOP) slow_block<C, CE, HASN, M_TOP>(&st, &t, blk, lane);
+            else if (m == M_END) slow_block<C, CE, HASN, M_END>(&st, &t, blk, lane);
+            else slow_block<C, CE, HASN, M_BOTH>(&st, &t, blk, lane);
             ++blk;
         }
     }
