@@ -77,6 +77,14 @@ class SequenceSet:
         self.lengths = [len(s) for s in self._keep]
 
     @classmethod
+    def from_fasta(cls, ctx: "Context", path: str):
+        """loadSequences equivalent: every record of a FASTA file, in file order (names in .names)."""
+        names, codes = load_fasta(path)
+        self = cls(ctx, codes, ascii=False)
+        self.names = names
+        return self
+
+    @classmethod
     def synthetic(cls, ctx: "Context", first_pair: int, n_pairs: int, length: int):
         """Pairs [first_pair, first_pair+n_pairs) of the benchmark generator, built and packed inside the
         library (sequence 2k = master, 2k+1 = slave); no host copy of the bases is kept."""
@@ -247,6 +255,25 @@ class ABlast:
         if n < 0:
             raise L.GamdpError("gamdp_find_hits failed")
         return list(buf[:n])
+
+
+def load_fasta(path: str):
+    """(names, code arrays) of a FASTA file through the library's loader (reference rules, no GPU needed)."""
+    lib = L.load_library()
+    h = C.c_void_p()
+    rc = lib.gamdp_fasta_open(path.encode(), C.byref(h))
+    if rc != 0:
+        raise L.GamdpError("gamdp_fasta_open(%s) failed with code %d" % (path, rc))
+    try:
+        names, codes = [], []
+        for i in range(lib.gamdp_fasta_count(h)):
+            names.append(lib.gamdp_fasta_name(h, i).decode())
+            n = C.c_uint64()
+            p = lib.gamdp_fasta_codes(h, i, C.byref(n))
+            codes.append(bytes(bytearray(p[:n.value])) if n.value else b"")
+        return names, codes
+    finally:
+        lib.gamdp_fasta_close(h)
 
 
 def encode(s) -> bytes:

@@ -10,6 +10,8 @@ SYMBOLS = [
     "gamdp_ctx_kernel_time", "gamdp_seqset_create", "gamdp_seqset_destroy", "gamdp_seqset_size",
     "gamdp_seqset_length", "gamdp_align_batch", "gamdp_align_merge_blocks", "gamdp_find_hits", "gamdp_encode",
     "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair", "gamdp_seqset_create_synth",
+    "gamdp_fasta_open", "gamdp_fasta_close", "gamdp_fasta_count", "gamdp_fasta_name", "gamdp_fasta_codes",
+    "gamdp_seqset_create_from_fasta",
 ]
 
 EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
@@ -110,5 +112,15 @@ def load_library():
     lib.gamdp_synth_pair.argtypes = [u64, u64, vp, vp]
     lib.gamdp_synth_pair.restype = u64
     lib.gamdp_seqset_create_synth.argtypes = [vp, u64, u32, u64, C.POINTER(vp)]
+    lib.gamdp_fasta_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.gamdp_fasta_close.argtypes = [vp]
+    lib.gamdp_fasta_close.restype = None
+    lib.gamdp_fasta_count.argtypes = [vp]
+    lib.gamdp_fasta_count.restype = u32
+    lib.gamdp_fasta_name.argtypes = [vp, u32]
+    lib.gamdp_fasta_name.restype = C.c_char_p
+    lib.gamdp_fasta_codes.argtypes = [vp, u32, C.POINTER(u64)]
+    lib.gamdp_fasta_codes.restype = C.POINTER(C.c_uint8)
+    lib.gamdp_seqset_create_from_fasta.argtypes = [vp, vp, C.POINTER(vp)]
     _lib = lib
     return lib

@@ -61,6 +61,7 @@ extern "C" {
 
 typedef struct gamdp_ctx gamdp_ctx;
 typedef struct gamdp_seqset gamdp_seqset;
+typedef struct gamdp_fasta gamdp_fasta;
 
 /* One find_alignment call.  Sequences are referenced by index into a seqset; *_rc selects the
  * reverse complement of that sequence (the reference reverse-complements the slave contig in
@@ -144,6 +145,17 @@ int gamdp_seqset_create(gamdp_ctx* ctx, const uint8_t* const* seqs, const uint64
 void gamdp_seqset_destroy(gamdp_seqset* set);
 uint32_t gamdp_seqset_size(const gamdp_seqset* set);
 uint64_t gamdp_seqset_length(const gamdp_seqset* set, uint32_t id);
+
+/* ---- FASTA loader (input side of the path; lib/include/assembly/io_contig.code.hpp:511-596) ------------- */
+/* Reads a (multi-)FASTA file with the reference's rules: name = header up to the first blank, every character
+ * other than newline / blank is a base through Nucleotide(char) (unknown -> N).  No GPU needed. */
+int gamdp_fasta_open(const char* path, gamdp_fasta** out);
+void gamdp_fasta_close(gamdp_fasta* f);
+uint32_t gamdp_fasta_count(const gamdp_fasta* f);
+const char* gamdp_fasta_name(const gamdp_fasta* f, uint32_t i);
+const uint8_t* gamdp_fasta_codes(const gamdp_fasta* f, uint32_t i, uint64_t* len);
+/* sequence i of the set = record i of the file */
+int gamdp_seqset_create_from_fasta(gamdp_ctx* ctx, const gamdp_fasta* f, gamdp_seqset** out);
 
 /* ---- L0: batch of independent banded alignments ------------------------------------------- */
 /* a sequences come from set_a, b sequences from set_b (may be the same set). */

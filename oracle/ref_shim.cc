@@ -11,6 +11,7 @@
 //   ABlast::findHits                      lib/src/alignment/ablast.cc:41-76
 //   reverse_complement / chop_begin       lib/include/assembly/contig.code.hpp:187-229, 257-261
 //   Nucleotide(char)                      lib/include/assembly/nucleotide.code.hpp:47-75
+//   readNextContigID / readNextSequence   lib/include/assembly/io_contig.code.hpp:511-563 (the loop of loadSequences, :578-590)
 #include <cstdint>
 #include <cstring>
 #include <list>
@@ -25,6 +26,8 @@
 #include "alignment/banded_smith_waterman.hpp"
 #include "alignment/my_alignment.hpp"
 #include "assembly/contig.hpp"
+#include "assembly/io_contig.hpp"
+#include <fstream>
 
 extern "C" {
 
@@ -157,6 +160,34 @@ uint64_t gamref_bench_pairs(const char* const* a, const uint64_t* alen, const ch
     for (int t = 0; t < (threads < 1 ? 1 : threads); t++) th.emplace_back(worker);
     for (auto& t : th) t.join();
     return cells.load();
+}
+
+
+// FASTA loading with the reference's own readers, in the loop of loadSequences (io_contig.code.hpp:578-590) but
+// with contigs sized by what is read (RefLength 0).  names: '\n'-separated; seqs: concatenated ACGTN chars.
+// Returns the number of records, -1 on a reference exception, -2 if a buffer is too small.
+int64_t gamref_load_fasta(const char* path, char* names, uint64_t names_cap, uint64_t* lens, uint64_t max_seqs,
+                          char* seqs, uint64_t seqs_cap)
+{
+    try {
+        std::ifstream ifs(path, std::ifstream::in);
+        uint64_t n = 0, np = 0, sp = 0;
+        while (!ifs.eof()) {
+            std::string name;
+            readNextContigID(ifs, name);
+            Contig ctg(name, size_t(0));
+            readNextSequence(ifs, ctg);
+            if (n >= max_seqs || np + name.size() + 1 > names_cap || sp + ctg.size() > seqs_cap) return -2;
+            std::memcpy(names + np, name.data(), name.size());
+            np += name.size();
+            names[np++] = '\n';
+            for (size_t i = 0; i < ctg.size(); i++) seqs[sp++] = char(ctg.at(i));
+            lens[n++] = ctg.size();
+        }
+        return int64_t(n);
+    } catch (...) {
+        return -1;
+    }
 }
 
 }  // extern "C"

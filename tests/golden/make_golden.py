@@ -13,6 +13,7 @@ source text.  Files written next to this script:
   l0_large.json       synthetic 50 kb pairs (generator = gamdp_oracle_synth_pair, keys stored)
   findhits.json       ABlast::findHits cases (checklist item 10)
   seqops.json         normalisation + reverse_complement cases (items 7, 13)
+  fasta.json          FASTA files and what the reference's readNextContigID/readNextSequence load from them
 """
 import ctypes
 import json
@@ -197,6 +198,43 @@ def seqops():
     return out
 
 
+FASTA_CASES = {
+    "plain": ">c1\nACGTACGT\n>c2\nTTTTGGGG\nCCCC\n",
+    "desc_and_case": ">ctg_1 length=12 cov=3.5\nacgtnACGTN\nryKM\n>ctg_2\tx\nAC\n",
+    "blank_lines_and_spaces": "\n\n>a\nAC GT\n\nAC\n \n>b\n\n>c\nT\n",
+    "no_trailing_newline": ">x\nACGT\n>y\nGG",
+    "crlf": ">w1\r\nACGT\r\nAC\r\n",
+    "single_long": ">only\n" + "ACGTTGCA" * 40 + "\n",
+    "empty_record_last": ">p\nAAAA\n>q\n",
+}
+
+
+def fasta():
+    import tempfile
+    lib = O.ref()
+    lib.gamref_load_fasta.restype = ctypes.c_int64
+    lib.gamref_load_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                      ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        for name, text in FASTA_CASES.items():
+            path = os.path.join(d, name + ".fa")
+            with open(path, "w", newline="") as f:
+                f.write(text)
+            names = ctypes.create_string_buffer(4096)
+            seqs = ctypes.create_string_buffer(1 << 16)
+            lens = (ctypes.c_uint64 * 64)()
+            n = lib.gamref_load_fasta(path.encode(), names, 4096, lens, 64, seqs, 1 << 16)
+            assert n >= 0, name
+            nm = names.value.decode().split("\n")[:n]
+            sq, pos = [], 0
+            for i in range(n):
+                sq.append(seqs.raw[pos:pos + lens[i]].decode())
+                pos += lens[i]
+            out.append(dict(name=name, text=text, names=nm, seqs=sq))
+    return out
+
+
 def main():
     assert O.ref() is not None, "needs /root/reference"
 
@@ -210,6 +248,7 @@ def main():
     dump("l0_large.json", large())
     dump("findhits.json", findhits())
     dump("seqops.json", seqops())
+    dump("fasta.json", fasta())
 
 
 if __name__ == "__main__":

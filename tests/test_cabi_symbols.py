@@ -77,3 +77,18 @@ def test_synthetic_generator_matches_oracle_generator():
         ss = ctypes.create_string_buffer(n + n // 8 + 64)
         sl = lib_o.gamdp_oracle_synth_pair(k, n, mm, ss)
         assert (m, s) == (mm.raw[:n], ss.raw[:sl])
+
+
+def test_fasta_loader_matches_reference_golden(tmp_path):
+    """gamdp_fasta_open against what the reference's readNextContigID/readNextSequence load (tests/golden/fasta.json)."""
+    for d in G.load("fasta.json"):
+        path = tmp_path / (d["name"] + ".fa")
+        with open(path, "w", newline="") as f:
+            f.write(d["text"])
+        names, codes = api.load_fasta(str(path))
+        assert names == d["names"], d["name"]
+        assert [api.decode(c) for c in codes] == d["seqs"], d["name"]
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>x\nAC\n")
+    with pytest.raises(gam.GamdpError):
+        api.load_fasta(str(bad))

@@ -92,3 +92,37 @@ def test_reference_exception_is_reported_per_merge_block():
     o1, aud1 = oracle_mb(scs[1], band=5)
     assert (mbs[1].status, mbs[1].align_ok, mbs[1].n_dp) == (o1.status, bool(o1.align_ok), o1.n_dp)
     assert [a.key() for a in mbs[1].audit] == aud1
+
+
+def test_standalone_tool_from_files(tmp_path):
+    """gamdp-align-mb (C++ over the C ABI): FASTA files + dumped merge blocks in, alignMergeBlock results out."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "gam_ngs_amd", "gamdp-align-mb")
+    scs = _l1cases.scenarios(901, 40)
+    with open(tmp_path / "master.fa", "w") as f:
+        for i, sc in enumerate(scs):
+            f.write(">m%d some description\n" % i)
+            for k in range(0, len(sc["master"]), 60):
+                f.write(sc["master"][k:k + 60] + "\n")
+    with open(tmp_path / "slave.fa", "w") as f:
+        for i, sc in enumerate(scs):
+            f.write(">s%d\n%s\n" % (i, sc["slave"]))
+    with open(tmp_path / "mb.tsv", "w") as f:
+        f.write("# dumped merge blocks\n")
+        for i, sc in enumerate(scs):
+            fields = ["m%d" % i, "s%d" % i] + [str(int(x)) for x in sc["tails"]] + [str(len(sc["blocks"]))]
+            for b in sc["blocks"]:
+                fields += [str(x) for x in b]
+            f.write("\t".join(fields) + "\n")
+    subprocess.run([tool, str(tmp_path / "master.fa"), str(tmp_path / "slave.fa"), str(tmp_path / "mb.tsv"), str(tmp_path / "out.tsv")],
+                   check=True, timeout=300)
+    rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "out.tsv") if not l.startswith("#")]
+    assert len(rows) == len(scs)
+    for sc, r in zip(scs, rows):
+        o, _ = oracle_mb(sc)
+        status, ok, rev, cset, ms, me, ss, se, ndp, cells = [int(x) for x in r[2:]]
+        assert (status, ok, cset, ndp, cells) == (o.status, o.align_ok, o.touched, o.n_dp, o.cells)
+        if o.touched:
+            assert (rev, ms, me, ss, se) == (o.align_rev, o.m_start, o.m_end, o.s_start, o.s_end)

@@ -1,0 +1,119 @@
+// gamdp-align-mb: run gam-merge's merge-block alignment step (PctgBuilder::alignMergeBlock for a whole list,
+// lib/src/pctg/BuildPctgFunctions.cc:82-84) on an MI355X from files, without the rest of gam-merge.
+//
+//   gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K]
+//
+// mergeblocks.tsv: one merge block per line, tab separated ('#' lines are comments):
+//   m_name s_name m_ltail m_rtail s_ltail s_rtail n_blocks  then n_blocks x (m_begin m_end s_begin s_end m_strand s_strand n_reads)
+// i.e. exactly what alignMergeBlock reads from the MergeBlock and from graph.getBlocks(mb.vertex); INTEGRATION.md
+// has the 15-line dump to add to the reference at the seam.  out.tsv gets the fields alignMergeBlock writes.
+//
+// It only uses the C ABI of include/gamdp.h (this file is also the C++ usage example of the library).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "gamdp.h"
+
+static void die(const std::string& m)
+{
+    std::fprintf(stderr, "gamdp-align-mb: %s\n", m.c_str());
+    std::exit(1);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 5) die("usage: gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K]");
+    unsigned band = GAMDP_DEFAULT_BAND;
+    int device = 0, repeat = 1;
+    for (int i = 5; i + 1 < argc; i += 2) {
+        if (!std::strcmp(argv[i], "--band")) band = (unsigned)std::atoi(argv[i + 1]);
+        else if (!std::strcmp(argv[i], "--device")) device = std::atoi(argv[i + 1]);
+        else if (!std::strcmp(argv[i], "--repeat")) repeat = std::atoi(argv[i + 1]);
+        else die(std::string("unknown option ") + argv[i]);
+    }
+
+    gamdp_fasta *fm = nullptr, *fs = nullptr;
+    if (gamdp_fasta_open(argv[1], &fm)) die(std::string("cannot load ") + argv[1]);
+    if (gamdp_fasta_open(argv[2], &fs)) die(std::string("cannot load ") + argv[2]);
+    std::map<std::string, int32_t> mid, sid;
+    for (uint32_t i = 0; i < gamdp_fasta_count(fm); i++) mid[gamdp_fasta_name(fm, i)] = (int32_t)i;
+    for (uint32_t i = 0; i < gamdp_fasta_count(fs); i++) sid[gamdp_fasta_name(fs, i)] = (int32_t)i;
+
+    std::vector<std::vector<gamdp_block>> blocks;
+    std::vector<gamdp_mb_in> in;
+    {
+        std::ifstream f(argv[3]);
+        if (!f) die(std::string("cannot open ") + argv[3]);
+        std::string line;
+        size_t ln = 0;
+        while (std::getline(f, line)) {
+            ln++;
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream ss(line);
+            std::string mn, sn;
+            int t[4];
+            unsigned nb;
+            if (!(ss >> mn >> sn >> t[0] >> t[1] >> t[2] >> t[3] >> nb)) die("bad merge-block line " + std::to_string(ln));
+            if (!mid.count(mn) || !sid.count(sn)) die("unknown contig on line " + std::to_string(ln));
+            blocks.emplace_back();
+            for (unsigned k = 0; k < nb; k++) {
+                gamdp_block b;
+                std::string ms, sst;
+                long long nr;
+                if (!(ss >> b.m_begin >> b.m_end >> b.s_begin >> b.s_end >> ms >> sst >> nr)) die("bad block on line " + std::to_string(ln));
+                b.m_strand = ms[0];
+                b.s_strand = sst[0];
+                b.n_reads = nr;
+                blocks.back().push_back(b);
+            }
+            gamdp_mb_in m;
+            m.m_id = mid[mn]; m.s_id = sid[sn];
+            m.m_ltail = (uint8_t)t[0]; m.m_rtail = (uint8_t)t[1]; m.s_ltail = (uint8_t)t[2]; m.s_rtail = (uint8_t)t[3];
+            m.n_blocks = nb;
+            m.blocks = nullptr;
+            in.push_back(m);
+        }
+        for (size_t i = 0; i < in.size(); i++) in[i].blocks = blocks[i].data();
+    }
+
+    gamdp_ctx* ctx = nullptr;
+    if (gamdp_ctx_create(device, &ctx)) die("no usable gfx950 GPU (libgamdp has no CPU fallback)");
+    gamdp_seqset *master = nullptr, *slave = nullptr;
+    if (gamdp_seqset_create_from_fasta(ctx, fm, &master) || gamdp_seqset_create_from_fasta(ctx, fs, &slave)) die(gamdp_last_error(ctx));
+
+    std::vector<gamdp_mb_out> out(in.size());
+    double best_s = 1e30;
+    for (int r = 0; r < repeat; r++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (gamdp_align_merge_blocks(ctx, master, slave, in.data(), in.size(), band, out.data(), nullptr, 0)) die(gamdp_last_error(ctx));
+        best_s = std::min(best_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+
+    unsigned long long cells = 0, ndp = 0, ok = 0, thrown = 0;
+    {
+        std::ofstream o(argv[4]);
+        o << "#m_name\ts_name\tstatus\talign_ok\talign_rev\tcoords_set\tm_start\tm_end\ts_start\ts_end\tn_dp\tcells\n";
+        for (size_t i = 0; i < in.size(); i++) {
+            const gamdp_mb_out& r = out[i];
+            o << gamdp_fasta_name(fm, (uint32_t)in[i].m_id) << '\t' << gamdp_fasta_name(fs, (uint32_t)in[i].s_id) << '\t' << (int)r.status
+              << '\t' << (int)r.align_ok << '\t' << (int)r.align_rev << '\t' << (int)r.coords_set << '\t' << r.m_start << '\t' << r.m_end
+              << '\t' << r.s_start << '\t' << r.s_end << '\t' << r.n_dp << '\t' << (unsigned long long)r.cells << '\n';
+            cells += r.cells; ndp += r.n_dp; ok += r.align_ok; thrown += (r.status != GAMDP_ST_OK);
+        }
+    }
+    std::fprintf(stderr, "gamdp-align-mb: %zu merge blocks, %llu find_alignment calls, %.3e cell updates, %llu align_ok, %llu would make the "
+                 "reference throw; %.3f s -> %.2f GCUPS (band %u)\n", in.size(), ndp, (double)cells, ok, thrown, best_s, cells / best_s / 1e9, band);
+    gamdp_seqset_destroy(master);
+    gamdp_seqset_destroy(slave);
+    gamdp_ctx_destroy(ctx);
+    gamdp_fasta_close(fm);
+    gamdp_fasta_close(fs);
+    return 0;
+}
