@@ -20,7 +20,9 @@
 //       v_max3_i32
 //       v_alignbit_b32 (append the 2-bit direction to the lane's 16-row direction word)
 //       v_and_b32     (strip the tag for the left chain / next row)
-//   Direction words (2 bit/cell) are the only per-cell HBM traffic: 16 B/lane coalesced stores.
+//   Direction words (2 bit/cell) are the only per-cell HBM traffic: 16 B/lane coalesced stores.  The two
+//   per-row sequence operands (one-hot of the incoming a base, score row of the b base) are expanded once per
+//   block by 16 lanes into per-wave LDS rings and read back with two ds_reads per row (LDS is otherwise idle).
 //
 //   Everything the reference treats specially is kept exact: row 0 (gap-free running max, :112-132),
 //   the pos==0 column (:141-155), force_start/force_end windows, the end-cell scan order (:174-212),
@@ -95,16 +97,16 @@ struct Tk {
 };
 
 
-// ---- per-wave LDS rings of pre-expanded sequence operands (kernels with 17 columns per lane) -------------
+// ---- per-wave LDS rings of pre-expanded sequence operands ---------------------------------------------------
 // Every row of every lane needs two operands derived from the sequences: the one-hot byte of the base entering
 // its a-window and the score row of its b base.  Expanding them costs 6 vector instructions per row per lane
 // (20 issue cycles of ~320).  Instead 16 lanes expand the 16 new a and b bases of a block ONCE, one block
 // ahead, into two LDS rings, and every lane fetches its operands with two ds_reads per row: the LDS pipe is
 // otherwise idle, so this takes the work off the vector ALU.
 //   ring A: entry k = one-hot (or v_perm selector) of a[A0 + k], A0 = a_base + begin_a - band; lane l needs
-//           k = tau + 16*(l+1) at row-time tau.  Stored transposed, pos = (k%16)*128 + (k/16)%128, so the 64
-//           lanes of a read (k = k0 + 16*l) hit 64 consecutive dwords (no bank conflict) and the 16 rows of a
-//           block are 16 compile-time offsets from one per-lane address.
+//           k = tau + (C-1)*(l+1) at row-time tau.  With 17 columns per lane it is stored transposed,
+//           pos = (k%16)*128 + (k/16)%128, so the 64 lanes of a read (k = k0 + 16*l) hit 64 consecutive dwords (no
+//           bank conflict) and the 16 rows of a block are 16 compile-time offsets from one per-lane address.
 //   ring B: entry k = score row(s) of b[b_base + begin_b + k]; lane l needs k = tau - l.  128 entries + a copy
 //           of the first 16 behind them so that the 16 rows of a block never wrap.
 //   (Kernels with fewer columns per lane -- lane stride C-1 not a multiple of 16 -- use the same rings with a
@@ -115,9 +117,6 @@ constexpr int RING_B = 128;
 __shared__ u32 s_ringA[RING_A + ROWS];
 __shared__ u32 s_ringB[2 * (RING_B + ROWS)];
 __shared__ int s_cap[2][2][20];  // side-capture scratch [pos==0 | pos==end_a][lane parity], see do_block
-
-template <int C>
-struct UseLds { static constexpr bool value = true; };
 
 // ring A geometry per column count: size = power of two >= 64*(C-1) + 32
 template <int C>
@@ -213,34 +212,22 @@ enum { M_FAST = 0, M_TOP = 1, M_END = 2, M_BOTH = 3 };
 
 template <int C, int CE, bool HASN, int MODE>
 __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t,
-                                         const int blk, const int lane, const int LE, const int kill_c,
-                                         const u32 abits, const u32 bbits, const u32 anb, const u32 bnb)
+                                         const int blk, const int lane, const int LE, const int kill_c)
 {
     const int tau0 = blk * ROWS;
 
-    // LDS operand path: one per-lane address per ring and block, the 16 rows are immediate offsets
-    const u32* ringA_lane = nullptr;
-    const u32* ringB_lane = nullptr;
-    if (UseLds<C>::value) {
-        // k = tau0 + r + (C-1)*(lane+1)
-        if (RingA<C>::transposed) ringA_lane = s_ringA + (((tau0 + (C - 1) * (lane + 1)) >> 4) & (RingA<C>::size / 16 - 1));
-        else ringA_lane = s_ringA + ((tau0 + (C - 1) * (lane + 1)) & (RingA<C>::size - 1));
-        ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));          // k = tau0 + r - lane
-    }
+    // operands come from the LDS rings: one per-lane address per ring and block, the 16 rows are immediate offsets
+    const u32* ringA_lane;  // k = tau0 + r + (C-1)*(lane+1)
+    if (RingA<C>::transposed) ringA_lane = s_ringA + (((tau0 + (C - 1) * (lane + 1)) >> 4) & (RingA<C>::size / 16 - 1));
+    else ringA_lane = s_ringA + ((tau0 + (C - 1) * (lane + 1)) & (RingA<C>::size - 1));
+    const u32* ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));  // k = tau0 + r - lane
 
     int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        u32 brow, bhi = 0;
-        if (UseLds<C>::value) {
-            W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * (RingA<C>::size / 16) : r];
-            brow = ringB_lane[2 * r];
-            if (HASN) bhi = ringB_lane[2 * r + 1];
-        } else {
-            const u32 ca = (abits >> (2 * r)) & 3u, cb = (bbits >> (2 * r)) & 3u;
-            W[C - 1 + r] = enc_a<HASN>(ca, HASN && ((anb >> r) & 1u));
-            enc_b<HASN>(cb, HASN && ((bnb >> r) & 1u), brow, bhi);
-        }
+        W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * (RingA<C>::size / 16) : r];
+        const u32 brow = ringB_lane[2 * r];
+        const u32 bhi = HASN ? ringB_lane[2 * r + 1] : 0u;
 
         // per-row values of the special modes
         constexpr bool TOP = (MODE & M_TOP) != 0, END = (MODE & M_END) != 0;
@@ -405,20 +392,14 @@ __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const i
     u32 W[C + 15];
     int Lin, Lout;
     load_state<C>(st, Lp, acc, W, Lin, Lout);
-    u32 abits = 0, bbits = 0, anb = 0, bnb = 0;
-    if (UseLds<C>::value) {
+    {
         // operands of this block are already in the LDS rings; expand the next block's 16 new bases
         const int T = (blk + 1) * ROWS;
         const int64_t ia = t.a_base + t.begin_a - t.band + T + (C - 1) * 64, ib = t.b_base + t.begin_b + T;
         ring_produce<C, HASN>(T, lane, fetch16(t.a2, ia), HASN ? fetch16n(t.an, ia) : 0u, fetch16(t.b2, ib),
                               HASN ? fetch16n(t.bn, ib) : 0u);
-    } else {
-        const int64_t sA = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1) + blk * ROWS;
-        const int64_t sB = t.b_base + t.begin_b - lane + blk * ROWS;
-        abits = fetch16(t.a2, sA); bbits = fetch16(t.b2, sB);
-        if (HASN) { anb = fetch16n(t.an, sA); bnb = fetch16n(t.bn, sB); }
     }
-    do_block<C, CE, HASN, MODE>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
+    do_block<C, CE, HASN, MODE>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
     store_state<C>(st, Lp, acc, W, Lin, Lout);
 }
 
@@ -435,65 +416,19 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
     u32 W[C + 15];
     int Lin, Lout;
     load_state<C>(st, Lp, acc, W, Lin, Lout);
-    if (UseLds<C>::value) {
-        // LDS operand path.  Invariant: on entry of block T the rings hold everything block T reads; the top of
-        // block T expands the 16 new bases of block T+16 from packed words that were requested one block earlier.
-        const int64_t iA0 = t.a_base + t.begin_a - t.band + (C - 1) * 64, iB0 = t.b_base + t.begin_b;
-        gcptr pa = t.a2 + (iA0 >> 4), pb = t.b2 + (iB0 >> 4);  // wave-uniform streams, one word per block
-        const u32 sha = (u32)(iA0 & 15) * 2u, shb = (u32)(iB0 & 15) * 2u;
-        u32 a_lo = pa[blk_begin + 1], a_hi = pa[blk_begin + 2], b_lo = pb[blk_begin + 1], b_hi = pb[blk_begin + 2];
-        u32 an_lo = 0, an_hi = 0, bn_lo = 0, bn_hi = 0;
-        if (HASN) {
-            const int64_t ia = iA0 + (int64_t)(blk_begin + 1) * ROWS, ib = iB0 + (int64_t)(blk_begin + 1) * ROWS;
-            an_lo = t.an[ia >> 5]; an_hi = t.an[(ia >> 5) + 1];
-            bn_lo = t.bn[ib >> 5]; bn_hi = t.bn[(ib >> 5) + 1];
-        }
-        asm volatile("" : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi), "+v"(Lin));
-        if (HASN) asm volatile("" : "+v"(an_lo), "+v"(an_hi), "+v"(bn_lo), "+v"(bn_hi));
-#pragma unroll
-        for (int c = 0; c < C; ++c) asm volatile("" : "+v"(Lp[c]), "+v"(acc[c]));
-#pragma unroll
-        for (int k = 0; k < C - 1; ++k) asm volatile("" : "+v"(W[k]));
-        for (int blk = blk_begin; blk < blk_end; ++blk) {
-            const int T = (blk + 1) * ROWS;
-            const u32 a_nx = pa[blk + 3], b_nx = pb[blk + 3];  // words of block blk+2, used at the next iteration
-            u32 an_lo_nx = 0, an_hi_nx = 0, bn_lo_nx = 0, bn_hi_nx = 0;
-            if (HASN) {
-                const int64_t ia = iA0 + T + ROWS, ib = iB0 + T + ROWS;
-                an_lo_nx = t.an[ia >> 5]; an_hi_nx = t.an[(ia >> 5) + 1];
-                bn_lo_nx = t.bn[ib >> 5]; bn_hi_nx = t.bn[(ib >> 5) + 1];
-            }
-            u32 anw = 0, bnw = 0;
-            if (HASN) {
-                anw = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((iA0 + T) & 31)) & 0xFFFFu;
-                bnw = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((iB0 + T) & 31)) & 0xFFFFu;
-            }
-            ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
-                                  __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
-            do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c, 0u, 0u, 0u, 0u);
-            a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
-            if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
-        }
-        store_state<C>(st, Lp, acc, W, Lin, Lout);
-        return;
-    }
-    // Per-lane sequence streams advance exactly 16 bases (= one 2-bit word) per block, so each block needs one
-    // new word per stream; it is requested one block ahead and only waited for at the top of the next block.
-    const int64_t sA0 = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * (lane + 1);  // base index of block 0
-    const int64_t sB0 = t.b_base + t.begin_b - lane;
-    gcptr pa = t.a2 + (sA0 >> 4), pb = t.b2 + (sB0 >> 4);
-    const u32 sha = (u32)(sA0 & 15) * 2u, shb = (u32)(sB0 & 15) * 2u;
-    u32 a_lo = pa[blk_begin], a_hi = pa[blk_begin + 1], b_lo = pb[blk_begin], b_hi = pb[blk_begin + 1];
-    // N planes (32 bases per word): two words per block, also one block ahead
+    // Invariant: on entry of block T the LDS rings hold everything block T reads; the top of block T expands the 16
+    // new bases of block T+16 from packed words that were requested one block earlier (so the hot loop never waits
+    // on a load it just issued, and never drains the direction stores in flight).
+    const int64_t iA0 = t.a_base + t.begin_a - t.band + (C - 1) * 64, iB0 = t.b_base + t.begin_b;
+    gcptr pa = t.a2 + (iA0 >> 4), pb = t.b2 + (iB0 >> 4);  // wave-uniform streams, one word per block
+    const u32 sha = (u32)(iA0 & 15) * 2u, shb = (u32)(iB0 & 15) * 2u;
+    u32 a_lo = pa[blk_begin + 1], a_hi = pa[blk_begin + 2], b_lo = pb[blk_begin + 1], b_hi = pb[blk_begin + 2];
     u32 an_lo = 0, an_hi = 0, bn_lo = 0, bn_hi = 0;
     if (HASN) {
-        const int64_t ia = sA0 + (int64_t)blk_begin * ROWS, ib = sB0 + (int64_t)blk_begin * ROWS;
+        const int64_t ia = iA0 + (int64_t)(blk_begin + 1) * ROWS, ib = iB0 + (int64_t)(blk_begin + 1) * ROWS;
         an_lo = t.an[ia >> 5]; an_hi = t.an[(ia >> 5) + 1];
         bn_lo = t.bn[ib >> 5]; bn_hi = t.bn[(ib >> 5) + 1];
     }
-    // Make everything loaded so far land BEFORE the loop: otherwise the compiler parks the `s_waitcnt vmcnt(0)`
-    // of these loads inside the loop (at their first use), where it would also drain the direction stores of
-    // the previous block on every iteration.
     asm volatile("" : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi), "+v"(Lin));
     if (HASN) asm volatile("" : "+v"(an_lo), "+v"(an_hi), "+v"(bn_lo), "+v"(bn_hi));
 #pragma unroll
@@ -501,22 +436,22 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
 #pragma unroll
     for (int k = 0; k < C - 1; ++k) asm volatile("" : "+v"(W[k]));
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        const int tau0 = blk * ROWS;
-        const u32 a_nx = pa[blk + 2], b_nx = pb[blk + 2];  // prefetch for block blk+1
+        const int T = (blk + 1) * ROWS;
+        const u32 a_nx = pa[blk + 3], b_nx = pb[blk + 3];  // words of block blk+2, used at the next iteration
         u32 an_lo_nx = 0, an_hi_nx = 0, bn_lo_nx = 0, bn_hi_nx = 0;
         if (HASN) {
-            const int64_t ia = sA0 + tau0 + ROWS, ib = sB0 + tau0 + ROWS;
+            const int64_t ia = iA0 + T + ROWS, ib = iB0 + T + ROWS;
             an_lo_nx = t.an[ia >> 5]; an_hi_nx = t.an[(ia >> 5) + 1];
             bn_lo_nx = t.bn[ib >> 5]; bn_hi_nx = t.bn[(ib >> 5) + 1];
         }
-        const u32 abits = __builtin_amdgcn_alignbit(a_hi, a_lo, sha);
-        const u32 bbits = __builtin_amdgcn_alignbit(b_hi, b_lo, shb);
-        u32 anb = 0, bnb = 0;
+        u32 anw = 0, bnw = 0;
         if (HASN) {
-            anb = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((sA0 + tau0) & 31)) & 0xFFFFu;
-            bnb = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((sB0 + tau0) & 31)) & 0xFFFFu;
+            anw = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((iA0 + T) & 31)) & 0xFFFFu;
+            bnw = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((iB0 + T) & 31)) & 0xFFFFu;
         }
-        do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c, abits, bbits, anb, bnb);
+        ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
+                              __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
+        do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
         a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
         if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
     }
@@ -833,7 +768,7 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
         for (int k = C - 1; k < C + 15; ++k) W[k] = 0;
     }
 
-    if (UseLds<C>::value) {
+    {
         // everything block 0 reads: ring A entries k < 16 + 64*(C-1), ring B entries k < 16
         const int64_t A0 = t.a_base + t.begin_a - w, BB = t.b_base + t.begin_b;
         for (int k = lane; k < ROWS + (C - 1) * 64; k += 64) {
