@@ -18,7 +18,7 @@ constexpr int SEQ_PAD_BASES = 4096;
 
 // resident waves per SIMD the kernels are register-budgeted for (4 SIMDs per CU)
 #ifndef GAMDP_WAVES_PER_SIMD
-#define GAMDP_WAVES_PER_SIMD 4
+#define GAMDP_WAVES_PER_SIMD 5
 #endif
 
 // one find_alignment call, pre-validated and pre-sized on the host

@@ -112,23 +112,26 @@ struct Tk {
 //   (Kernels with fewer columns per lane -- lane stride C-1 not a multiple of 16 -- use the same rings with a
 //   plain layout pos = k % size plus a 16-entry copy behind the ring; their ring-A reads are 2..8-way bank
 //   conflicted, which the otherwise idle LDS pipe absorbs.)
-constexpr int RING_A = 2048;
+constexpr int RING_A = 16 * 72;  // 1152 entries: the transposed ring of the 17-column kernels (72 columns of 16)
 constexpr int RING_B = 128;
 __shared__ u32 s_ringA[RING_A + ROWS];
 __shared__ u32 s_ringB[2 * (RING_B + ROWS)];
 __shared__ int s_cap[2][2][20];  // side-capture scratch [pos==0 | pos==end_a][lane parity], see do_block
 
-// ring A geometry per column count: size = power of two >= 64*(C-1) + 32
+// ring A geometry per column count.  Plain layout: size = power of two >= 64*(C-1) + 32.  Transposed layout (C = 17):
+// 16 rows of COLS = 72 dwords, entry k at (k%16)*COLS + (k/16)%COLS (72 >= 1056/16 + 2; a multiple of 8 keeps the
+// 64 lanes of a read on 64 distinct banks).
 template <int C>
 struct RingA {
     static constexpr bool transposed = ((C - 1) % 16 == 0);
     static constexpr int span = 64 * (C - 1) + 32;
-    static constexpr int size = span <= 128 ? 128 : span <= 256 ? 256 : span <= 512 ? 512 : span <= 1024 ? 1024 : 2048;
-    static_assert(span <= RING_A, "ring A too small");
+    static constexpr int size = span <= 128 ? 128 : span <= 256 ? 256 : span <= 512 ? 512 : 1024;
+    static constexpr int COLS = 72;
+    static_assert(transposed ? (span <= 16 * (COLS - 2)) : (span <= size && size + ROWS <= RING_A + ROWS), "ring A too small");
     // position of entry k
     static __device__ __forceinline__ int pos(int k)
     {
-        if (transposed) return ((k & 15) * (size / 16)) | ((k >> 4) & (size / 16 - 1));
+        if (transposed) return (k & 15) * COLS + (int)((u32)(k >> 4) % (u32)COLS);
         return k & (size - 1);
     }
     // write entry k (plain layout keeps a copy of the first 16 entries behind the ring so that the 16 rows of a
@@ -218,14 +221,14 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 
     // operands come from the LDS rings: one per-lane address per ring and block, the 16 rows are immediate offsets
     const u32* ringA_lane;  // k = tau0 + r + (C-1)*(lane+1)
-    if (RingA<C>::transposed) ringA_lane = s_ringA + (((tau0 + (C - 1) * (lane + 1)) >> 4) & (RingA<C>::size / 16 - 1));
+    if (RingA<C>::transposed) ringA_lane = s_ringA + (u32)((tau0 + (C - 1) * (lane + 1)) >> 4) % (u32)RingA<C>::COLS;
     else ringA_lane = s_ringA + ((tau0 + (C - 1) * (lane + 1)) & (RingA<C>::size - 1));
     const u32* ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));  // k = tau0 + r - lane
 
     int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * (RingA<C>::size / 16) : r];
+        W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
         const u32 brow = ringB_lane[2 * r];
         const u32 bhi = HASN ? ringB_lane[2 * r + 1] : 0u;
 
