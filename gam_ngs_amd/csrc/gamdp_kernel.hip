@@ -226,6 +226,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     const u32* ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));  // k = tau0 + r - lane
 
     int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
+    const u32 tagK = (CE >= 0 && CE < C - 1 && lane == LE) ? 0x80000001u : 1u;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
@@ -254,12 +255,10 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
             int D;
             if (HASN) D = Lp[c] + (int)__builtin_amdgcn_perm(bhi, brow, W[r + c]);
             else D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
-            int Uc = (c < C - 1) ? (Lp[(c < C - 1) ? c + 1 : c] | 1) : (x | 1);
-            if (CE >= 0) {
-                if (c == CE && CE < C - 1) Uc = (lane == LE) ? NEG : Uc;
-            } else {
-                Uc = (c == kill_c) ? NEG : Uc;
-            }
+            // tag the `up` source; the tuned kernels drop the `up` of the last band column (static position CE of
+            // lane LE) in the same v_or: tagK also sets the sign bit there (all live G4 values are >= 0)
+            int Uc = (c < C - 1) ? (int)((u32)Lp[(c < C - 1) ? c + 1 : c] | ((CE >= 0 && c == CE) ? tagK : 1u)) : (x | 1);
+            if (CE < 0) Uc = (c == kill_c) ? NEG : Uc;
             const int R = imax3(D, Uc, L);
             acc[c] = __builtin_amdgcn_alignbit((u32)R, acc[c], 2);
             const int Lc = R & ~3;
