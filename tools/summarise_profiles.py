@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>_* (written by tools/collect_profiles.sh on the GPU box) into the files under profiles/:
+<tag>_kernel_stats.csv, <tag>_kernel_trace.csv (k_align rows), <tag>_bench_under_rocprof.log,
+<tag>_pmc_counters.json and <tag>_traffic.json.  Usage: tools/summarise_profiles.py r01 [pairs len band]"""
+import csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+pairs, length, band = (int(x) for x in (sys.argv[2:5] if len(sys.argv) >= 5 else (100000, 50000, 512)))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[-1]
+
+
+shutil.copy(one(f"{tag}_trace/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+with open(one(f"{tag}_trace/**/*_kernel_trace.csv")) as f, open(os.path.join(dst, f"{tag}_kernel_trace.csv"), "w") as g:
+    rd = csv.reader(f)
+    wr = csv.writer(g)
+    wr.writerow(next(rd))
+    for row in rd:
+        if any("k_align" in c for c in row):
+            wr.writerow(row)
+with open(os.path.join(src, f"{tag}_bench.log")) as f:
+    lines = [l for l in f if l.startswith("{")]
+with open(os.path.join(dst, f"{tag}_bench_under_rocprof.log"), "w") as g:
+    g.write(lines[-1])
+
+counters, kernel = {}, None
+for name in ("fetch", "write", "sq", "sq2", "sq3"):
+    try:
+        path = one(f"{tag}_{name}/**/*_counter_collection.csv")
+    except SystemExit:
+        continue
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if "k_align" not in row["Kernel_Name"]:
+                continue
+            kernel = row["Kernel_Name"]
+            counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+with open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w") as g:
+    json.dump({"kernel": kernel, "launches": 1, "counters": counters}, g, indent=1)
+
+# MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts a 128-B read request as 64 B,
+# so the read side is doubled; the write side is taken as is.
+fetch = counters["FETCH_SIZE"] * 1024.0 * 2.0
+write = counters["WRITE_SIZE"] * 1024.0
+with open(os.path.join(dst, f"{tag}_traffic.json"), "w") as g:
+    json.dump({"round": 1, "kernel": kernel, "workload": {"pairs_per_launch": pairs, "len": length, "band": band},
+               "FETCH_SIZE_KB": counters["FETCH_SIZE"], "WRITE_SIZE_KB": counters["WRITE_SIZE"],
+               "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --steps 1 --warmup 0 "
+                       "--no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B read requests "
+                       "at 64 B); WRITE_SIZE taken as is"}, g, indent=1)
+print(json.dumps(counters, indent=1))
+print("hbm bytes per launch %.4g (fetch %.4g, write %.4g)" % (fetch + write, fetch, write))
