@@ -64,6 +64,18 @@ def cpu_baseline(length, band, first_pair, budget_pairs):
                       (budget_pairs, length, band, threads, dt)}
 
 
+def kernel_name(band):
+    """The k_align instantiation the library picks for N-free contigs of this band (gamdp_host.cpp pick_kernel)."""
+    n = "true" if os.environ.get("GAMDP_DIAG_FORCE_N") else "false"
+    if band == 512:
+        return "k_align<17,4,%s>" % n
+    if band == 150:
+        return "k_align<5,0,%s>" % n
+    y = 2 * band + 1
+    c = next(c for c in (2, 3, 5, 9, 17) if y <= c * 64)
+    return "k_align<%d,-1,true>" % c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +185,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_bytes_per_launch": traffic_bytes,
                          "algorithmic_bytes_per_launch": cells_per_launch * B_ALG,
-                         "kernel": "k_align<17,4,false>", "kernel_ms_per_launch": avg_launch_s * 1e3,
+                         "kernel": kernel_name(args.band), "kernel_ms_per_launch": avg_launch_s * 1e3,
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
         if not args.no_cpu_baseline:

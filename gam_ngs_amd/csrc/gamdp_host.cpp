@@ -312,7 +312,9 @@ static int prepare_task(const ITask& it, Prepared& pr)
         const int64_t up = std::min<int64_t>(hi, FORCE_MAXGAP_);
         if (lo <= up && up >= (int64_t)alen) return GAMDP_ST_OUT_OF_RANGE;
     }
-    const bool has_n = it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
+    // GAMDP_DIAG_FORCE_N (tests, profiling): run N-free inputs through the N-aware kernels as well
+    static const bool diag_force_n = std::getenv("GAMDP_DIAG_FORCE_N") != nullptr;
+    const bool has_n = diag_force_n || it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
     pr.kid = pick_kernel((int)band, has_n);
     const int C = kernel_cols(pr.kid);
     const int LE = (int)((Y - 1) / (u64)C);

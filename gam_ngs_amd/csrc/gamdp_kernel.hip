@@ -15,7 +15,7 @@
 //   `up` and `left` is 0 and `diag` adds 4*(S+16)+2 in {86 match, 50 mismatch, 66 N-vs-base}; the two low
 //   bits carry the winner (2 diag, 1 up, 0 left) so ONE v_max3_i32 picks the value and, on ties, the
 //   traceback preference diag > up > left of the reference (:273-304).  A cell is
-//       v_dot4_u32_u8 (one-hot(a) . scorerow(b) + H_diag)   | v_perm_b32 + v_add for the N-aware kernels
+//       v_dot4_u32_u8 (one-hot(a) . scorerow(b) + H_diag)   | v_dot8_u32_u4 over 5 letters in the N-aware kernels
 //       v_or_b32      (tag the `up` source)
 //       v_max3_i32
 //       v_alignbit_b32 (append the 2-bit direction to the lane's 16-row direction word)
@@ -103,7 +103,7 @@ struct Tk {
 // (20 issue cycles of ~320).  Instead 16 lanes expand the 16 new a and b bases of a block ONCE, one block
 // ahead, into two LDS rings, and every lane fetches its operands with two ds_reads per row: the LDS pipe is
 // otherwise idle, so this takes the work off the vector ALU.
-//   ring A: entry k = one-hot (or v_perm selector) of a[A0 + k], A0 = a_base + begin_a - band; lane l needs
+//   ring A: entry k = one-hot (bytes for dot4, nibbles for dot8) of a[A0 + k], A0 = a_base + begin_a - band; lane l needs
 //           k = tau + (C-1)*(l+1) at row-time tau.  With 17 columns per lane it is stored transposed,
 //           pos = (k%16)*128 + (k/16)%128, so the 64 lanes of a read (k = k0 + 16*l) hit 64 consecutive dwords (no
 //           bank conflict) and the 16 rows of a block are 16 compile-time offsets from one per-lane address.
@@ -115,7 +115,7 @@ struct Tk {
 constexpr int RING_A = 16 * 72;  // 1152 entries: the transposed ring of the 17-column kernels (72 columns of 16)
 constexpr int RING_B = 128;
 __shared__ u32 s_ringA[RING_A + ROWS];
-__shared__ u32 s_ringB[2 * (RING_B + ROWS)];
+__shared__ u32 s_ringB[RING_B + ROWS];
 __shared__ int s_cap[2][2][20];  // side-capture scratch [pos==0 | pos==end_a][lane parity], see do_block
 
 // ring A geometry per column count.  Plain layout: size = power of two >= 64*(C-1) + 32.  Transposed layout (C = 17):
@@ -147,15 +147,18 @@ struct RingA {
 template <bool HASN>
 __device__ __forceinline__ u32 enc_a(u32 code2, bool isn)
 {
-    if (HASN) return 0x0C0C0C00u | (isn ? 4u : code2);  // v_perm selector: byte0 = table[code]
-    return 1u << (code2 * 8u);                          // one-hot byte per base
+    // N-aware: one-hot NIBBLE (value 4) per letter A T C G N + a constant 10 in nibble 5, for v_dot8_u32_u4
+    if (HASN) return (4u << ((isn ? 4u : code2) * 4u)) | (10u << 20);
+    return 1u << (code2 * 8u);  // one-hot byte per base, for v_dot4_u32_u8
 }
 template <bool HASN>
-__device__ __forceinline__ void enc_b(u32 code2, bool isn, u32& brow, u32& bhi)
+__device__ __forceinline__ u32 enc_b(u32 code2, bool isn)
 {
-    // table entry(a) = 4*(S(a,b)+16)+2 : match 86, N-vs-base 66, mismatch 50; bhi = entry for a == N
-    if (HASN && isn) { brow = 0x42424242u; bhi = 0x56u; }
-    else { brow = 0x32323232u + (0x24u << (code2 * 8u)); bhi = 0x42u; }
+    // what a diag step adds: 4*(S(a,b)+16)+2 = 86 match (N-N included), 66 N-vs-base, 50 mismatch.
+    // dot4 form: byte(a) = that value.  dot8 form: 50 = 10*5 from the constant nibbles, + 4*9 = 36 on a match,
+    // + 4*4 = 16 when exactly one side is N.
+    if (HASN) return isn ? (0x4444u | (9u << 16) | (5u << 20)) : ((9u << (code2 * 4u)) | (4u << 16) | (5u << 20));
+    return 0x32323232u + (0x24u << (code2 * 8u));
 }
 
 // lanes 0..15 expand the 16 new entries of the block whose first row-time is T
@@ -165,12 +168,10 @@ __device__ __forceinline__ void ring_produce(const int T, const int lane, const 
     if (lane < ROWS) {
         const int kA = T + (C - 1) * 64 + lane;
         RingA<C>::put(kA, enc_a<HASN>((aw >> (2 * lane)) & 3u, HASN && ((anw >> lane) & 1u)));
-        u32 brow, bhi;
-        enc_b<HASN>((bw >> (2 * lane)) & 3u, HASN && ((bnw >> lane) & 1u), brow, bhi);
+        const u32 brow = enc_b<HASN>((bw >> (2 * lane)) & 3u, HASN && ((bnw >> lane) & 1u));
         const int pb = (T + lane) & (RING_B - 1);
-        s_ringB[2 * pb] = brow;
-        s_ringB[2 * pb + 1] = bhi;
-        if (pb < ROWS) { s_ringB[2 * (pb + RING_B)] = brow; s_ringB[2 * (pb + RING_B) + 1] = bhi; }
+        s_ringB[pb] = brow;
+        if (pb < ROWS) s_ringB[pb + RING_B] = brow;
     }
 }
 
@@ -223,15 +224,14 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     const u32* ringA_lane;  // k = tau0 + r + (C-1)*(lane+1)
     if (RingA<C>::transposed) ringA_lane = s_ringA + (u32)((tau0 + (C - 1) * (lane + 1)) >> 4) % (u32)RingA<C>::COLS;
     else ringA_lane = s_ringA + ((tau0 + (C - 1) * (lane + 1)) & (RingA<C>::size - 1));
-    const u32* ringB_lane = s_ringB + 2 * ((tau0 - lane) & (RING_B - 1));  // k = tau0 + r - lane
+    const u32* ringB_lane = s_ringB + ((tau0 - lane) & (RING_B - 1));  // k = tau0 + r - lane
 
     int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
     const u32 tagK = (CE >= 0 && CE < C - 1 && lane == LE) ? 0x80000001u : 1u;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
-        const u32 brow = ringB_lane[2 * r];
-        const u32 bhi = HASN ? ringB_lane[2 * r + 1] : 0u;
+        const u32 brow = ringB_lane[r];
 
         // per-row values of the special modes
         constexpr bool TOP = (MODE & M_TOP) != 0, END = (MODE & M_END) != 0;
@@ -253,7 +253,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
         // each wave independent work between the dependent max3 -> and -> max3 steps.)
         auto cell = [&](const int c) __attribute__((always_inline)) {
             int D;
-            if (HASN) D = Lp[c] + (int)__builtin_amdgcn_perm(bhi, brow, W[r + c]);
+            if (HASN) D = (int)__builtin_amdgcn_udot8(W[r + c], brow, (u32)Lp[c], false);
             else D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
             // tag the `up` source; the tuned kernels drop the `up` of the last band column (static position CE of
             // lane LE) in the same v_or: tagK also sets the sign bit there (all live G4 values are >= 0)
@@ -758,13 +758,7 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
         const u32 an = HASN ? fetch16n(t.an, s0) : 0u;
 #pragma unroll
         for (int k = 0; k < C - 1; ++k) {
-            u32 ca = (ab >> (2 * k)) & 3u;
-            if (HASN) {
-                if ((an >> k) & 1u) ca = 4;
-                W[k] = 0x0C0C0C00u | ca;
-            } else {
-                W[k] = 1u << (ca * 8u);
-            }
+            W[k] = enc_a<HASN>((ab >> (2 * k)) & 3u, HASN && ((an >> k) & 1u));
         }
 #pragma unroll
         for (int k = C - 1; k < C + 15; ++k) W[k] = 0;
@@ -781,10 +775,9 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
         }
         if (lane < ROWS) {
             const int64_t ib = BB + lane;
-            u32 brow, bhi;
-            enc_b<HASN>((t.b2[ib >> 4] >> ((ib & 15) * 2)) & 3u, HASN && ((t.bn[ib >> 5] >> (ib & 31)) & 1u), brow, bhi);
-            s_ringB[2 * lane] = brow; s_ringB[2 * lane + 1] = bhi;
-            s_ringB[2 * (lane + RING_B)] = brow; s_ringB[2 * (lane + RING_B) + 1] = bhi;
+            const u32 brow = enc_b<HASN>((t.b2[ib >> 4] >> ((ib & 15) * 2)) & 3u, HASN && ((t.bn[ib >> 5] >> (ib & 31)) & 1u));
+            s_ringB[lane] = brow;
+            s_ringB[lane + RING_B] = brow;
         }
     }
     store_state<C>(st, Lp, acc, W, Lin, Lout);

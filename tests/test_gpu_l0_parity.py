@@ -173,3 +173,16 @@ def test_row_cap_and_long_tasks_against_oracle():
             if want_ops:
                 assert r.ops == ops
     assert res[0].cells == 500000 * 11
+
+
+def test_n_aware_kernels_on_every_case_in_a_fresh_process():
+    """GAMDP_DIAG_FORCE_N routes N-free inputs through the N-aware (v_dot8) kernels too: the random, medium and
+    large-pair tests of this file must still be bit-exact.  The switch is read once per process, hence the child."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_DIAG_FORCE_N"):
+        pytest.skip("already inside the forced-N child")
+    env = dict(os.environ, GAMDP_DIAG_FORCE_N="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__),
+                        "-k", "random_cases or medium_pairs or golden_large or row_cap"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

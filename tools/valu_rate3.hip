@@ -8,6 +8,8 @@
 #include <cstdlib>
 
 #define DOT4(d, w, b, l) asm volatile("v_dot4_u32_u8 %0, %1, %2, %3" : "=v"(d) : "v"(w), "v"(b), "v"(l))
+#define DOT8(d, w, b, l) asm volatile("v_dot8_u32_u4 %0, %1, %2, %3" : "=v"(d) : "v"(w), "v"(b), "v"(l))
+#define PERMADD(d, w, b, l) asm volatile("v_perm_b32 %0, %2, %2, %1\n v_add_u32 %0, %0, %3" : "=&v"(d) : "v"(w), "v"(b), "v"(l))
 #define OR1(d, s) asm volatile("v_or_b32 %0, 1, %1" : "=v"(d) : "v"(s))
 #define MAX3(d, a, b, c) asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
 #define ALB(acc, r) asm volatile("v_alignbit_b32 %0, %1, %0, 2" : "+v"(acc) : "v"(r))
@@ -42,14 +44,18 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int rows, unsigned seed)
                 AND4(Lp[c], R[c]);
                 if (c == 0) SHL1(x, Lp[0]);
             }
-        } else if (VARIANT == 1 || VARIANT == 4 || VARIANT == 5) {
+        } else if (VARIANT == 1 || VARIANT == 4 || VARIANT == 5 || VARIANT == 6 || VARIANT == 7) {
             DOT4(D[0], W[0], brow, Lp[0]); DOT4(D[1], W[1], brow, Lp[1]); OR1(U[0], Lp[1]); OR1(U[1], Lp[2]);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 MAX3(R[c], D[c], (VARIANT == 5) ? Lp[(c + 1) % C] : U[c], (c == 0) ? Lin : Lp[(c + C - 1) % C]);
                 AND4(Lp[c], R[c]);
                 if (VARIANT != 5 && c + 2 < C) OR1(U[c + 2], (c + 3 < C) ? Lp[c + 3] : x);
-                if (c + 2 < C) DOT4(D[c + 2], W[c + 2], brow, Lp[c + 2]);
+                if (c + 2 < C) {
+                    if (VARIANT == 6) DOT8(D[c + 2], W[c + 2], brow, Lp[c + 2]);
+                    else if (VARIANT == 7) PERMADD(D[c + 2], W[c + 2], brow, Lp[c + 2]);
+                    else DOT4(D[c + 2], W[c + 2], brow, Lp[c + 2]);
+                }
                 if (VARIANT != 4) ALB(acc[c], R[c]);
                 if (c == 0) SHL1(x, Lp[0]);
             }
@@ -147,5 +153,7 @@ int main()
     run<3>("3: max3 and alb dot4 or        (B A B B A')", d);
     run<4>("4: variant 1 without alignbit", d);
     run<5>("5: variant 1 without or", d);
+    run<6>("6: variant 1 with v_dot8_u32_u4", d);
+    run<7>("7: variant 1 with v_perm + v_add (N-aware)", d);
     return 0;
 }
