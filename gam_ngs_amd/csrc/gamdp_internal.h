@@ -76,6 +76,13 @@ struct Ctx {
     ~Ctx();
 };
 
+// what gamdp_fasta points to: the host-side RefSequence (names + 1 B/base codes), no GPU involved
+struct Fasta {
+    std::vector<std::string> names;
+    std::vector<std::vector<uint8_t>> codes;
+    std::string err;
+};
+
 // ABlast::findHits (ablast.cc:41-76) on code arrays
 void find_hits(const uint8_t* a, u64 alen, u64 a_start, u64 a_end, const uint8_t* b, u64 blen, u64 b_start, u64 b_end,
                u64 word, std::vector<uint32_t>& hits);

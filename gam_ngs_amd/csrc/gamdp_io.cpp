@@ -21,12 +21,6 @@
 
 namespace gamdp {
 
-struct Fasta {
-    std::vector<std::string> names;
-    std::vector<std::vector<uint8_t>> codes;
-    std::string err;
-};
-
 static inline uint8_t enc(char ch)
 {
     switch (ch) {
@@ -91,6 +85,27 @@ int gamdp_fasta_open(const char* path, gamdp_fasta** out)
         std::fprintf(stderr, "libgamdp: %s: %s\n", path, f->err.c_str());
         delete f;
         return rc;
+    }
+    *out = reinterpret_cast<gamdp_fasta*>(f);
+    return 0;
+}
+
+int gamdp_fasta_create(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, int is_ascii,
+                       gamdp_fasta** out)
+{
+    if (!out || (n && (!names || !seqs || !lens))) return GAMDP_EINVAL;
+    *out = nullptr;
+    Fasta* f = new (std::nothrow) Fasta();
+    if (!f) return GAMDP_ENOMEM;
+    for (uint32_t i = 0; i < n; i++) {
+        f->names.emplace_back(names[i] ? names[i] : "");
+        std::vector<uint8_t> v(lens[i]);
+        for (uint64_t k = 0; k < lens[i]; k++) {
+            if (is_ascii) v[k] = enc((char)seqs[i][k]);
+            else if (seqs[i][k] > 4) { delete f; return GAMDP_EINVAL; }
+            else v[k] = seqs[i][k];
+        }
+        f->codes.push_back(std::move(v));
     }
     *out = reinterpret_cast<gamdp_fasta*>(f);
     return 0;

@@ -12,6 +12,10 @@ SYMBOLS = [
     "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair", "gamdp_seqset_create_synth",
     "gamdp_fasta_open", "gamdp_fasta_close", "gamdp_fasta_count", "gamdp_fasta_name", "gamdp_fasta_codes",
     "gamdp_seqset_create_from_fasta",
+    "gamdp_fasta_create", "gamdp_merge_lists_prepare", "gamdp_zscore_vote", "gamdp_pctgs_create", "gamdp_pctgs_destroy",
+    "gamdp_pctgs_last_error", "gamdp_pctgs_add_graph", "gamdp_pctgs_finish", "gamdp_pctgs_count",
+    "gamdp_pctgs_merged_count", "gamdp_pctgs_codes", "gamdp_pctgs_rows", "gamdp_pctgs_contig_use",
+    "gamdp_pctgs_write_fasta", "gamdp_pctgs_write_descriptors",
 ]
 
 EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
@@ -61,6 +65,21 @@ class MbOut(C.Structure):
                 ("m_start", C.c_int32), ("m_end", C.c_int32), ("s_start", C.c_int32), ("s_end", C.c_int32),
                 ("n_dp", C.c_uint32), ("cells", C.c_uint64)]
 
+
+class MBlock(C.Structure):
+    _fields_ = [("m_id", C.c_int32), ("m_start", C.c_int32), ("m_end", C.c_int32), ("s_id", C.c_int32),
+                ("s_start", C.c_int32), ("s_end", C.c_int32), ("align_rev", C.c_uint8), ("align_ok", C.c_uint8),
+                ("m_ltail", C.c_uint8), ("m_rtail", C.c_uint8), ("s_ltail", C.c_uint8), ("s_rtail", C.c_uint8),
+                ("ext_slave_next", C.c_uint8), ("ext_slave_prev", C.c_uint8), ("m_rev", C.c_uint8),
+                ("s_rev", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+
+
+class PctgRow(C.Structure):
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("ctg_id", C.c_int32), ("reversed", C.c_uint8),
+                ("is_master", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+
+
+REGION_VOTE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
 
 _lib = None
 
@@ -122,5 +141,28 @@ def load_library():
     lib.gamdp_fasta_codes.argtypes = [vp, u32, C.POINTER(u64)]
     lib.gamdp_fasta_codes.restype = C.POINTER(C.c_uint8)
     lib.gamdp_seqset_create_from_fasta.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.gamdp_fasta_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int,
+                                       C.POINTER(vp)]
+    lib.gamdp_merge_lists_prepare.argtypes = [vp, vp, C.POINTER(MBlock), C.POINTER(u32), u32, C.c_uint,
+                                              C.POINTER(MBlock), u64, C.POINTER(u32), u32, C.POINTER(u32)]
+    lib.gamdp_zscore_vote.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
+    lib.gamdp_pctgs_create.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.gamdp_pctgs_destroy.argtypes = [vp]
+    lib.gamdp_pctgs_destroy.restype = None
+    lib.gamdp_pctgs_last_error.argtypes = [vp]
+    lib.gamdp_pctgs_last_error.restype = C.c_char_p
+    lib.gamdp_pctgs_add_graph.argtypes = [vp, C.POINTER(MBlock), C.POINTER(u32), u32, REGION_VOTE_FN, vp]
+    lib.gamdp_pctgs_finish.argtypes = [vp]
+    lib.gamdp_pctgs_count.argtypes = [vp]
+    lib.gamdp_pctgs_count.restype = u32
+    lib.gamdp_pctgs_merged_count.argtypes = [vp]
+    lib.gamdp_pctgs_merged_count.restype = u32
+    lib.gamdp_pctgs_codes.argtypes = [vp, u32, C.POINTER(u64)]
+    lib.gamdp_pctgs_codes.restype = C.POINTER(C.c_uint8)
+    lib.gamdp_pctgs_rows.argtypes = [vp, u32, C.POINTER(PctgRow), u32]
+    lib.gamdp_pctgs_rows.restype = u32
+    lib.gamdp_pctgs_contig_use.argtypes = [vp, vp, vp]
+    lib.gamdp_pctgs_write_fasta.argtypes = [vp, C.c_char_p]
+    lib.gamdp_pctgs_write_descriptors.argtypes = [vp, C.c_char_p]
     _lib = lib
     return lib

@@ -178,6 +178,82 @@ void gamdp_encode(const char* chars, uint64_t n, uint8_t* codes);
 void gamdp_decode(const uint8_t* codes, uint64_t n, char* chars);
 void gamdp_revcomp(uint8_t* codes, uint64_t n);
 
+/* ---- post-alignment stage: merge lists -> paired contigs -> .gam.fasta / .pctgs ----- */
+/* Host only (no GPU, no ctx).  Replaces, for one assembly graph, BuildPctgFunctions.cc:86-92 after the align loop:
+ * splitMergeBlocksByAlign / ByDirection / sortMergeBlocksByDirection / splitMergeBlocksByInclusions
+ * (PctgBuilder.cc:667-723, 543-665, 507-541, 291-505) and buildPctgs (PctgBuilder.cc:172-288); and, for the whole
+ * run, the id assignment, the single-contig pctgs and the two writers of src/Merge.cc:380-385, 437-465. */
+
+/* a host-side assembly from memory (what gamdp_fasta_open builds from a file): names[i] may be NULL */
+int gamdp_fasta_create(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n,
+                       int is_ascii, gamdp_fasta** out);
+
+/* MergeBlock as the post-alignment stage sees it (MergeDescriptor.hpp:40-69 without vertex/valid). */
+typedef struct gamdp_mblock {
+    int32_t m_id, m_start, m_end;
+    int32_t s_id, s_start, s_end;
+    uint8_t align_rev, align_ok;
+    uint8_t m_ltail, m_rtail, s_ltail, s_rtail;
+    uint8_t ext_slave_next, ext_slave_prev;   /* carried and updated like the reference; nothing reads them */
+    uint8_t m_rev, s_rev;                     /* written by the direction stage */
+    uint8_t pad_[2];
+} gamdp_mblock;
+
+/* CtgInPctgInfo (lib/include/pctg/CtgInPctgInfo.hpp:44-69): one row of a paired contig's merge list */
+typedef struct gamdp_pctg_row {
+    int64_t start, end;        /* first / last base taken from the contig, on the strand it is used on */
+    int32_t ctg_id;
+    uint8_t reversed, is_master;
+    uint8_t pad_[2];
+} gamdp_pctg_row;
+
+#define GAMDP_STAGE_ALIGN      1u   /* splitMergeBlocksByAlign      */
+#define GAMDP_STAGE_DIRECTION  2u   /* splitMergeBlocksByDirection  */
+#define GAMDP_STAGE_SORT       4u   /* sortMergeBlocksByDirection   */
+#define GAMDP_STAGE_INCLUSIONS 8u   /* splitMergeBlocksByInclusions */
+#define GAMDP_STAGE_ALL        15u
+
+/* The list surgery alone (stages applied in the reference's order, selected by the mask).  Lists are passed flat:
+ * blocks holds list 0, then list 1, ...; list_sizes their lengths.  Returns GAMDP_ENOMEM (with *n_out_lists set)
+ * when the output does not fit. */
+int gamdp_merge_lists_prepare(const gamdp_fasta* master, const gamdp_fasta* slave, const gamdp_mblock* blocks,
+                              const uint32_t* list_sizes, uint32_t n_lists, unsigned stages, gamdp_mblock* out_blocks,
+                              uint64_t cap_blocks, uint32_t* out_sizes, uint32_t cap_lists, uint32_t* n_out_lists);
+
+/* appendBlocksRegionToPctg asks the BAMs which assembly to trust when the two copies of a block region differ in
+ * length by more than 3 % (computeZScore, PctgBuilder.cc:147-168).  The host supplies that decision:
+ * return 0 = take the master's copy, 1 = the slave's, < 0 = error (the graph is dropped).  Coordinates are the ones
+ * the reference passes (strand coordinates of the merge block). */
+typedef int (*gamdp_region_vote_fn)(void* user, int32_t m_id, int32_t m_start, int32_t m_end, int32_t s_id,
+                                    int32_t s_start, int32_t s_end);
+/* the evidence count of PctgBuilder.cc:155-168 on two z-score vectors: 0 = master, 1 = slave */
+int gamdp_zscore_vote(const double* master_z, const double* slave_z, size_t n);
+
+typedef struct gamdp_pctgs gamdp_pctgs;   /* std::list<PairedContig> of one gam-merge run */
+int gamdp_pctgs_create(const gamdp_fasta* master, const gamdp_fasta* slave, gamdp_pctgs** out);
+void gamdp_pctgs_destroy(gamdp_pctgs* p);
+const char* gamdp_pctgs_last_error(const gamdp_pctgs* p);
+/* One graph's merge lists (after gamdp_align_merge_blocks filled align_ok/align_rev/m_start..s_end): list surgery +
+ * buildPctgs; the resulting paired contigs are appended in list order.  On error nothing of this graph is kept
+ * (the reference drops a graph whose worker throws, ThreadedBuildPctg.cc:322-329). */
+int gamdp_pctgs_add_graph(gamdp_pctgs* p, const gamdp_mblock* blocks, const uint32_t* list_sizes, uint32_t n_lists,
+                          gamdp_region_vote_fn vote, void* user);
+/* ids 0.. in insertion order, then one paired contig per master contig no paired contig uses (ascending id, empty
+ * contigs skipped): src/Merge.cc:380-385, 437-452, BuildPctgFunctions.cc:111-129 */
+int gamdp_pctgs_finish(gamdp_pctgs* p);
+uint32_t gamdp_pctgs_count(const gamdp_pctgs* p);
+uint32_t gamdp_pctgs_merged_count(const gamdp_pctgs* p);   /* how many came from merge lists (old_pctg_id) */
+const uint8_t* gamdp_pctgs_codes(const gamdp_pctgs* p, uint32_t i, uint64_t* len);
+/* merge list of paired contig i: returns its length, writes the first cap rows */
+uint32_t gamdp_pctgs_rows(const gamdp_pctgs* p, uint32_t i, gamdp_pctg_row* out, uint32_t cap);
+/* which contigs any paired contig touches (getMasterCtgIdSet / getSlaveIds; Merge.cc:418-424 needs the slave side
+ * for .notmerged.fasta); either pointer may be NULL */
+int gamdp_pctgs_contig_use(const gamdp_pctgs* p, uint8_t* master_used, uint8_t* slave_used);
+/* ".gam.fasta": >PairedContig_<id>, 60 bases per line (io_contig.code.hpp:246-262 + the endl of Merge.cc:458) */
+int gamdp_pctgs_write_fasta(const gamdp_pctgs* p, const char* path);
+/* ".pctgs" (PairedContig.cc:305-349) */
+int gamdp_pctgs_write_descriptors(const gamdp_pctgs* p, const char* path);
+
 /* Synthetic pair k of the benchmark workload (BASELINE.json config 5): master = len uniform ACGT
  * codes, slave = master with 3 % substitutions, 1 % insertions, 1 % deletions (splitmix64 keyed by
  * k).  slave must hold len + len/8 + 64 codes; returns the slave length. */

@@ -12,6 +12,8 @@
 //   reverse_complement / chop_begin       lib/include/assembly/contig.code.hpp:187-229, 257-261
 //   Nucleotide(char)                      lib/include/assembly/nucleotide.code.hpp:47-75
 //   readNextContigID / readNextSequence   lib/include/assembly/io_contig.code.hpp:511-563 (the loop of loadSequences, :578-590)
+//   PairedContig, CtgInPctgInfo, operator<<(ostream&, const Contig&), writePctgDescriptors
+//                                         lib/src/pctg/PairedContig.cc:33-189, 305-349; io_contig.code.hpp:246-262
 #include <cstdint>
 #include <cstring>
 #include <list>
@@ -27,7 +29,10 @@
 #include "alignment/my_alignment.hpp"
 #include "assembly/contig.hpp"
 #include "assembly/io_contig.hpp"
+#include "assembly/RefSequence.hpp"
+#include "pctg/PairedContig.hpp"
 #include <fstream>
+#include <sstream>
 
 extern "C" {
 
@@ -188,6 +193,65 @@ int64_t gamref_load_fasta(const char* path, char* names, uint64_t names_cap, uin
     } catch (...) {
         return -1;
     }
+}
+
+
+// Renders paired contigs with the reference's own classes and writers.  The caller describes each paired contig as
+// a list of pieces (assembly, contig id, first, last, reversed flag); a piece is appended the way the reference's
+// appendMasterToPctg / appendSlaveToPctg do it through PairedContig's public interface (resize + operator[] +
+// getMergeList().push_back(CtgInPctgInfo(...)), PctgBuilder.cc:102-132 -- those members themselves cannot be compiled
+// here).  A piece whose source flag is set is cut from the reference's reverse_complement() of the contig.
+// pieces: 7 int64 per piece = {pctg index, is_master, ctg id, start, end, reversed flag of the row, source is
+// reverse-complemented}, sorted by pctg index.
+// Output: fasta text (".gam.fasta": `os << pctg << std::endl` per paired contig, src/Merge.cc:458) and the .pctgs text.
+int64_t gamref_render_pctgs(const char* const* m_names, const char* const* m_seqs, uint32_t n_master,
+                            const char* const* s_names, const char* const* s_seqs, uint32_t n_slave,
+                            const int64_t* pieces, uint64_t n_pieces, uint32_t n_pctgs, uint64_t first_single,
+                            char* fasta_out, uint64_t fasta_cap, char* desc_out, uint64_t desc_cap)
+{
+    RefSequence masterRef(n_master), slaveRef(n_slave);
+    for (uint32_t i = 0; i < n_master; i++) {
+        masterRef[i].RefName = m_names[i];
+        masterRef[i].Sequence = new Contig(make_contig(m_seqs[i], std::strlen(m_seqs[i])));
+        masterRef[i].Sequence->set_name(m_names[i]);
+        masterRef[i].RefLength = (int32_t)masterRef[i].Sequence->size();
+    }
+    for (uint32_t i = 0; i < n_slave; i++) {
+        slaveRef[i].RefName = s_names[i];
+        slaveRef[i].Sequence = new Contig(make_contig(s_seqs[i], std::strlen(s_seqs[i])));
+        slaveRef[i].Sequence->set_name(s_names[i]);
+        slaveRef[i].RefLength = (int32_t)slaveRef[i].Sequence->size();
+    }
+    std::list<PairedContig> result;
+    uint64_t at = 0;
+    for (uint32_t p = 0; p < n_pctgs; p++) {
+        PairedContig pctg;
+        while (at < n_pieces && pieces[7 * at] == (int64_t)p) {
+            const int64_t* q = pieces + 7 * at++;
+            const bool is_master = q[1] != 0;
+            const int32_t id = (int32_t)q[2];
+            Contig ctg(*(is_master ? masterRef[id].Sequence : slaveRef[id].Sequence));
+            if (q[6]) reverse_complement(ctg);
+            if (is_master) pctg.addMasterCtgId(id); else pctg.addSlaveCtgId(id);
+            int64_t idx = pctg.size();
+            pctg.resize(pctg.size() + (q[4] - q[3] + 1));
+            for (int64_t i = q[3]; i <= q[4]; i++) pctg[idx++] = ctg.at(i);
+            pctg.getMergeList().push_back(CtgInPctgInfo(id, q[3], q[4], q[5] != 0, is_master));
+        }
+        result.push_back(pctg);
+    }
+    uint64_t pctg_id = 0;  // src/Merge.cc:380-385
+    for (std::list<PairedContig>::iterator it = result.begin(); it != result.end(); ++it) it->setId(pctg_id++);
+    std::ostringstream fa, de;
+    for (std::list<PairedContig>::const_iterator it = result.begin(); it != result.end(); ++it) fa << *it << std::endl;
+    writePctgDescriptors(de, result, masterRef, slaveRef, first_single);
+    for (uint32_t i = 0; i < n_master; i++) delete masterRef[i].Sequence;
+    for (uint32_t i = 0; i < n_slave; i++) delete slaveRef[i].Sequence;
+    const std::string f = fa.str(), d = de.str();
+    if (f.size() + 1 > fasta_cap || d.size() + 1 > desc_cap) return -1;
+    std::memcpy(fasta_out, f.c_str(), f.size() + 1);
+    std::memcpy(desc_out, d.c_str(), d.size() + 1);
+    return (int64_t)f.size();
 }
 
 }  // extern "C"

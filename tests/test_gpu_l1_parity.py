@@ -126,3 +126,57 @@ def test_standalone_tool_from_files(tmp_path):
         assert (status, ok, cset, ndp, cells) == (o.status, o.align_ok, o.touched, o.n_dp, o.cells)
         if o.touched:
             assert (rev, ms, me, ss, se) == (o.align_rev, o.m_start, o.m_end, o.s_start, o.s_end)
+
+
+def test_standalone_tool_through_to_gam_fasta(tmp_path):
+    """gamdp-align-mb --pctgs: merge blocks grouped into graphs and merge lists -> alignment on the GPU -> list surgery,
+    buildPctgs, ids, single-contig pctgs -> .gam.fasta / .pctgs, against the two CPU restatements chained together."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import pctg_oracle as PO
+    tool = os.path.join(root, "gam_ngs_amd", "gamdp-align-mb")
+    scs = _l1cases.scenarios(77, 60)
+    code = {"A": 0, "T": 1, "C": 2, "G": 3}
+    master = [[code.get(ch, 4) for ch in sc["master"].upper()] for sc in scs]
+    slave = [[code.get(ch, 4) for ch in sc["slave"].upper()] for sc in scs]
+    with open(tmp_path / "master.fa", "w") as f:
+        for i, sc in enumerate(scs):
+            f.write(">m%d\n%s\n" % (i, sc["master"]))
+    with open(tmp_path / "slave.fa", "w") as f:
+        for i, sc in enumerate(scs):
+            f.write(">s%d\n%s\n" % (i, sc["slave"]))
+    graphs, dropped = [], 0
+    with open(tmp_path / "mb.tsv", "w") as f:
+        for g0 in range(0, len(scs), 6):          # a graph = 6 merge blocks in lists of 1..3
+            f.write("#graph\n")
+            lists, thrown = [], False
+            for i in range(g0, min(g0 + 6, len(scs))):
+                if (i - g0) in (0, 1, 3):
+                    f.write("#list\n")
+                    lists.append([])
+                sc = scs[i]
+                fields = ["m%d" % i, "s%d" % i] + [str(int(x)) for x in sc["tails"]] + [str(len(sc["blocks"]))]
+                for b in sc["blocks"]:
+                    fields += [str(x) for x in b]
+                f.write("\t".join(fields) + "\n")
+                o, _ = oracle_mb(sc)
+                thrown |= o.status != 0
+                t = [int(x) for x in sc["tails"]]
+                lists[-1].append(dict(m_id=i, s_id=i, m_start=o.m_start, m_end=o.m_end, s_start=o.s_start, s_end=o.s_end,
+                                      align_ok=int(o.align_ok), align_rev=int(o.align_rev) if o.touched else 0,
+                                      m_ltail=t[0], m_rtail=t[1], s_ltail=t[2], s_rtail=t[3], ext_slave_next=1,
+                                      ext_slave_prev=1, m_rev=0, s_rev=0))
+            if thrown:
+                dropped += 1
+            else:
+                graphs.append(lists)
+    subprocess.run([tool, str(tmp_path / "master.fa"), str(tmp_path / "slave.fa"), str(tmp_path / "mb.tsv"), str(tmp_path / "out.tsv"),
+                    "--pctgs", str(tmp_path / "run"), "--vote", "master"], check=True, timeout=300)
+    want, merged = PO.run(graphs, master, slave, lambda mb: 0)
+    assert merged > 10
+    assert open(tmp_path / "run.gam.fasta").read() == PO.render_fasta(want)
+    assert open(tmp_path / "run.pctgs").read() == PO.render_descriptors(want, merged, ["m%d" % i for i in range(len(scs))],
+                                                                      ["s%d" % i for i in range(len(scs))])

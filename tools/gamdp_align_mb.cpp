@@ -2,11 +2,19 @@
 // lib/src/pctg/BuildPctgFunctions.cc:82-84) on an MI355X from files, without the rest of gam-merge.
 //
 //   gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K]
+//                  [--pctgs PREFIX] [--vote master|slave|fail]
 //
 // mergeblocks.tsv: one merge block per line, tab separated ('#' lines are comments):
 //   m_name s_name m_ltail m_rtail s_ltail s_rtail n_blocks  then n_blocks x (m_begin m_end s_begin s_end m_strand s_strand n_reads)
 // i.e. exactly what alignMergeBlock reads from the MergeBlock and from graph.getBlocks(mb.vertex); INTEGRATION.md
 // has the 15-line dump to add to the reference at the seam.  out.tsv gets the fields alignMergeBlock writes.
+// A line "#graph" starts the next assembly graph and "#list" the next merge list of the current graph.
+//
+// With --pctgs the rest of buildPctg runs as well (list surgery + buildPctgs, BuildPctgFunctions.cc:86-92, then ids,
+// single-contig pctgs and the writers of src/Merge.cc:380-465): PREFIX.gam.fasta and PREFIX.pctgs are written.  A graph
+// holding a merge block on which the reference would have thrown contributes nothing, like ThreadedBuildPctg.cc:322-329.
+// --vote says what to do when a block region needs the BAM evidence of computeZScore (PctgBuilder.cc:147-168), which
+// this tool does not have: take the master's copy, the slave's, or stop (default).
 //
 // It only uses the C ABI of include/gamdp.h (this file is also the C++ usage example of the library).
 #include <chrono>
@@ -27,16 +35,27 @@ static void die(const std::string& m)
     std::exit(1);
 }
 
+static int g_vote = -1;  // --vote: what stands in for the BAM evidence
+static int region_vote(void*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) { return g_vote < 0 ? GAMDP_EINVAL : g_vote; }
+
 int main(int argc, char** argv)
 {
-    if (argc < 5) die("usage: gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K]");
+    if (argc < 5) die("usage: gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K] "
+                      "[--pctgs PREFIX] [--vote master|slave|fail]");
     unsigned band = GAMDP_DEFAULT_BAND;
     int device = 0, repeat = 1;
+    std::string pctg_prefix;
     for (int i = 5; i + 1 < argc; i += 2) {
         if (!std::strcmp(argv[i], "--band")) band = (unsigned)std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--repeat")) repeat = std::atoi(argv[i + 1]);
-        else die(std::string("unknown option ") + argv[i]);
+        else if (!std::strcmp(argv[i], "--pctgs")) pctg_prefix = argv[i + 1];
+        else if (!std::strcmp(argv[i], "--vote")) {
+            if (!std::strcmp(argv[i + 1], "master")) g_vote = 0;
+            else if (!std::strcmp(argv[i + 1], "slave")) g_vote = 1;
+            else if (!std::strcmp(argv[i + 1], "fail")) g_vote = -1;
+            else die("--vote takes master, slave or fail");
+        } else die(std::string("unknown option ") + argv[i]);
     }
 
     gamdp_fasta *fm = nullptr, *fs = nullptr;
@@ -48,6 +67,8 @@ int main(int argc, char** argv)
 
     std::vector<std::vector<gamdp_block>> blocks;
     std::vector<gamdp_mb_in> in;
+    std::vector<uint32_t> graph_of, list_of;  // per merge block
+    uint32_t graph = 0, list = 0;
     {
         std::ifstream f(argv[3]);
         if (!f) die(std::string("cannot open ") + argv[3]);
@@ -55,6 +76,8 @@ int main(int argc, char** argv)
         size_t ln = 0;
         while (std::getline(f, line)) {
             ln++;
+            if (line.compare(0, 6, "#graph") == 0) { if (!in.empty()) { graph++; list = 0; } continue; }
+            if (line.compare(0, 5, "#list") == 0) { if (!in.empty() && graph_of.back() == graph) list++; continue; }
             if (line.empty() || line[0] == '#') continue;
             std::istringstream ss(line);
             std::string mn, sn;
@@ -79,6 +102,8 @@ int main(int argc, char** argv)
             m.n_blocks = nb;
             m.blocks = nullptr;
             in.push_back(m);
+            graph_of.push_back(graph);
+            list_of.push_back(list);
         }
         for (size_t i = 0; i < in.size(); i++) in[i].blocks = blocks[i].data();
     }
@@ -110,6 +135,42 @@ int main(int argc, char** argv)
     }
     std::fprintf(stderr, "gamdp-align-mb: %zu merge blocks, %llu find_alignment calls, %.3e cell updates, %llu align_ok, %llu would make the "
                  "reference throw; %.3f s -> %.2f GCUPS (band %u)\n", in.size(), ndp, (double)cells, ok, thrown, best_s, cells / best_s / 1e9, band);
+    if (!pctg_prefix.empty()) {
+        gamdp_pctgs* pc = nullptr;
+        if (gamdp_pctgs_create(fm, fs, &pc)) die("gamdp_pctgs_create failed");
+        size_t dropped = 0, i = 0;
+        while (i < in.size()) {
+            size_t j = i;
+            bool thrown_here = false;
+            std::vector<gamdp_mblock> mbs;
+            std::vector<uint32_t> sizes;
+            while (j < in.size() && graph_of[j] == graph_of[i]) {
+                if (sizes.empty() || list_of[j] != list_of[j - 1]) sizes.push_back(0);
+                const gamdp_mb_out& r = out[j];
+                thrown_here |= r.status != GAMDP_ST_OK;
+                gamdp_mblock b;
+                std::memset(&b, 0, sizeof b);
+                b.m_id = in[j].m_id; b.s_id = in[j].s_id;
+                b.m_ltail = in[j].m_ltail; b.m_rtail = in[j].m_rtail; b.s_ltail = in[j].s_ltail; b.s_rtail = in[j].s_rtail;
+                b.align_ok = r.align_ok; b.align_rev = r.align_rev;
+                b.m_start = r.m_start; b.m_end = r.m_end; b.s_start = r.s_start; b.s_end = r.s_end;
+                b.ext_slave_next = b.ext_slave_prev = 1;  // PctgBuilder.cc:915-916
+                mbs.push_back(b);
+                sizes.back()++;
+                j++;
+            }
+            if (thrown_here) dropped++;
+            else if (gamdp_pctgs_add_graph(pc, mbs.data(), sizes.data(), (uint32_t)sizes.size(), region_vote, nullptr))
+                die(std::string("graph ") + std::to_string(graph_of[i]) + ": " + gamdp_pctgs_last_error(pc) + " (see --vote)");
+            i = j;
+        }
+        if (gamdp_pctgs_finish(pc)) die("gamdp_pctgs_finish failed");
+        if (gamdp_pctgs_write_fasta(pc, (pctg_prefix + ".gam.fasta").c_str()) || gamdp_pctgs_write_descriptors(pc, (pctg_prefix + ".pctgs").c_str()))
+            die("cannot write " + pctg_prefix + ".gam.fasta / .pctgs");
+        std::fprintf(stderr, "gamdp-align-mb: %u paired contigs (%u merged, %zu graphs dropped) -> %s.gam.fasta, %s.pctgs\n", gamdp_pctgs_count(pc),
+                     gamdp_pctgs_merged_count(pc), dropped, pctg_prefix.c_str(), pctg_prefix.c_str());
+        gamdp_pctgs_destroy(pc);
+    }
     gamdp_seqset_destroy(master);
     gamdp_seqset_destroy(slave);
     gamdp_ctx_destroy(ctx);
