@@ -11,6 +11,7 @@
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -374,11 +375,27 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
     }
 
     static const bool diag_skip_tb = std::getenv("GAMDP_DIAG_SKIP_TRACEBACK") != nullptr;
+    static const bool diag_timing = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<Prepared> prep(n);
+    std::vector<int> prep_status(n);
+    {
+        // validation + descriptor of every task: independent per task, spread over host threads for big batches
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned nthr = n >= 8192 ? hw : 1;
+        auto run = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) prep_status[i] = prepare_task(tasks[i], prep[i]); };
+        if (nthr == 1) run(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k < nthr; k++) th.emplace_back(run, n * k / nthr, n * (k + 1) / nthr);
+            for (auto& t : th) t.join();
+        }
+    }
     std::vector<std::vector<u32>> groups(K_COUNT);
     u64 ops_total = 0;
     for (size_t i = 0; i < n; i++) {
-        const int st = prepare_task(tasks[i], prep[i]);
+        const int st = prep_status[i];
         if (st != GAMDP_ST_OK) {
             std::memset(&out[i], 0, sizeof(out[i]));
             out[i].status = (uint8_t)st;
@@ -396,6 +413,7 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         groups[prep[i].kid].push_back((u32)i);
     }
 
+    const double ms_prep = since(t_begin);
     int rc_ = grow(this, d_results, cap_results, n);
     if (rc_) return rc_;
     if (ops_total) { rc_ = grow(this, d_ops, cap_ops, ops_total); if (rc_) return rc_; }
@@ -486,6 +504,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             d_cursor = nullptr;
             HIPCHK(this, hipMalloc(&d_cursor, launches.size() * sizeof(u32)));
         }
+        const double ms_plan = since(t_begin) - ms_prep;
+        const auto t_gpu = std::chrono::steady_clock::now();
         HIPCHK(this, hipMemcpyAsync(d_tasks, h_tasks, n_host_tasks * sizeof(DevTask), hipMemcpyHostToDevice, stream));
         HIPCHK(this, hipMemsetAsync(d_cursor, 0, std::max<size_t>(64, launches.size()) * sizeof(u32), stream));
         while (events.size() < launches.size()) {
@@ -510,6 +530,10 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         std::vector<uint8_t> hops(ops_total);
         if (ops_total) HIPCHK(this, hipMemcpyAsync(hops.data(), d_ops, ops_total, hipMemcpyDeviceToHost, stream));
         HIPCHK(this, hipStreamSynchronize(stream));
+        const double ms_gpu = since(t_gpu);
+        if (diag_timing)
+            std::fprintf(stderr, "libgamdp align: %zu tasks, %zu launches: prepare %.2f ms, plan+stage %.2f ms, upload+kernels+download %.2f ms\n",
+                         n, launches.size(), ms_prep, ms_plan, ms_gpu);
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
