@@ -274,6 +274,41 @@ static int pick_kernel(int band, bool has_n)
     return K_GEN_C17;
 }
 
+// fn(lo, hi) over [0, n) on up to 16 host threads (batches of a few thousand tasks are not worth a thread)
+template <class F>
+static void parallel_for(size_t n, F fn)
+{
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nthr = n >= 8192 ? hw : 1;
+    if (nthr == 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nthr; k++) th.emplace_back(fn, n * k / nthr, n * (k + 1) / nthr);
+    for (auto& t : th) t.join();
+}
+
+// ids (ascending on entry) -> stable order of decreasing key[id]; LSD radix sort, 3 passes of 11 bits (keys < 2^33)
+static void sort_by_key_desc(std::vector<u32>& ids, const std::vector<u64>& key)
+{
+    const size_t n = ids.size();
+    if (n < 2) return;
+    if (n < 4096) {
+        std::stable_sort(ids.begin(), ids.end(), [&](u32 x, u32 y) { return key[x] > key[y]; });
+        return;
+    }
+    u64 kmax = 0;
+    for (u32 i : ids) kmax = std::max(kmax, key[i]);
+    std::vector<u32> tmp(n);
+    std::vector<u32>*src = &ids, *dst = &tmp;
+    for (unsigned shift = 0; shift < 64 && (kmax >> shift) != 0; shift += 11) {
+        size_t count[2049] = {0};
+        for (u32 i : *src) count[2047 - ((key[i] >> shift) & 2047) + 1]++;   // inverted digit: descending order
+        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+        for (u32 i : *src) (*dst)[count[2047 - ((key[i] >> shift) & 2047)]++] = i;
+        std::swap(src, dst);
+    }
+    if (src != &ids) ids.swap(tmp);
+}
+
 struct Prepared {
     DevTask dt;
     int kid;
@@ -380,18 +415,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<Prepared> prep(n);
     std::vector<int> prep_status(n);
-    {
-        // validation + descriptor of every task: independent per task, spread over host threads for big batches
-        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        const unsigned nthr = n >= 8192 ? hw : 1;
-        auto run = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) prep_status[i] = prepare_task(tasks[i], prep[i]); };
-        if (nthr == 1) run(0, n);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned k = 0; k < nthr; k++) th.emplace_back(run, n * k / nthr, n * (k + 1) / nthr);
-            for (auto& t : th) t.join();
-        }
-    }
+    // validation + descriptor of every task: independent per task, spread over host threads for big batches
+    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) prep_status[i] = prepare_task(tasks[i], prep[i]); });
     std::vector<std::vector<u32>> groups(K_COUNT);
     u64 ops_total = 0;
     for (size_t i = 0; i < n; i++) {
@@ -441,16 +466,15 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         cap_pinned = want;
     }
     u64 n_host_tasks = 0;
+    std::vector<u64> cells_key(n);
+    for (size_t i = 0; i < n; i++) cells_key[i] = prep[i].cells;
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; };
     std::vector<Launch> launches;
     const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(0);
     for (int kid = 0; kid < K_COUNT; kid++) {
         auto& g = groups[kid];
         if (g.empty()) continue;
-        std::sort(g.begin(), g.end(), [&](u32 x, u32 y) {
-            if (prep[x].cells != prep[y].cells) return prep[x].cells > prep[y].cells;
-            return x < y;
-        });
+        sort_by_key_desc(g, cells_key);  // longest tasks first (LPT); ties keep the caller's order
         // One launch per group if slots sized for its largest direction matrix leave enough resident
         // waves; otherwise peel off the tasks with big matrices into their own launch and retry.
         std::vector<std::vector<u32>> work;
@@ -483,7 +507,11 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)cur.size();
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
             L.n_slots = (u32)std::min<u64>(want, fit);
-            for (u32 i : cur) h_tasks[n_host_tasks++] = prep[i].dt;
+            {
+                DevTask* dst = h_tasks + n_host_tasks;
+                parallel_for(cur.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) dst[k] = prep[cur[k]].dt; });
+                n_host_tasks += cur.size();
+            }
             launches.push_back(L);
         }
     }
@@ -538,19 +566,23 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
         }
-        for (u64 q = 0; q < n_host_tasks; q++) {
-            const DevTask& d = h_tasks[q];
-            const u32 i = d.res_idx;
-            fill_result(hres[i], prep[i].cells, out[i]);
-            if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
-                const u64 len = std::min<u64>(out[i].length, d.ops_cap);
-                // the kernel wrote ops in traceback order: reverse into the caller's buffer
-                uint8_t* dst = ops->ops_buf + ops->ops_off[i];
-                const uint8_t* src = hops.data() + d.ops_off;
-                if (out[i].length <= d.ops_cap) for (u64 k = 0; k < len; k++) dst[k] = src[len - 1 - k];
-                else for (u64 k = 0; k < len; k++) dst[k] = 0xFF;  // truncated: not reconstructible
+        const auto t_fill = std::chrono::steady_clock::now();
+        parallel_for(n_host_tasks, [&](size_t lo, size_t hi) {
+            for (size_t q = lo; q < hi; q++) {
+                const DevTask& d = h_tasks[q];
+                const u32 i = d.res_idx;
+                fill_result(hres[i], prep[i].cells, out[i]);
+                if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
+                    const u64 len = std::min<u64>(out[i].length, d.ops_cap);
+                    // the kernel wrote ops in traceback order: reverse into the caller's buffer
+                    uint8_t* dst = ops->ops_buf + ops->ops_off[i];
+                    const uint8_t* src = hops.data() + d.ops_off;
+                    if (out[i].length <= d.ops_cap) for (u64 k = 0; k < len; k++) dst[k] = src[len - 1 - k];
+                    else for (u64 k = 0; k < len; k++) dst[k] = 0xFF;  // truncated: not reconstructible
+                }
             }
-        }
+        });
+        if (diag_timing) std::fprintf(stderr, "libgamdp align: results %.2f ms\n", since(t_fill));
     }
     return 0;
 }
@@ -639,11 +671,13 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     const SeqSet* sa = reinterpret_cast<const SeqSet*>(set_a);
     const SeqSet* sb = reinterpret_cast<const SeqSet*>(set_b);
     std::vector<ITask> it(n);
-    for (size_t i = 0; i < n; i++) {
-        const gamdp_task& t = tasks[i];
-        it[i] = ITask{sa, sb, t.a_id, t.b_id, t.a_off, t.b_off, t.a_rc != 0, t.b_rc != 0, t.force_start != 0,
-                      t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
-    }
+    parallel_for(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const gamdp_task& t = tasks[i];
+            it[i] = ITask{sa, sb, t.a_id, t.b_id, t.a_off, t.b_off, t.a_rc != 0, t.b_rc != 0, t.force_start != 0,
+                          t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
+        }
+    });
     return c->align(it, out, ops);
 }
 
