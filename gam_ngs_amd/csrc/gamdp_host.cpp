@@ -309,13 +309,6 @@ static void sort_by_key_desc(std::vector<u32>& ids, const std::vector<u64>& key)
     if (src != &ids) ids.swap(tmp);
 }
 
-struct Prepared {
-    DevTask dt;
-    int kid;
-    u64 cells;
-    u64 dir_words;
-};
-
 // returns GAMDP_ST_OK when the task has to run on the GPU, otherwise its final status
 static int prepare_task(const ITask& it, Prepared& pr)
 {
@@ -387,10 +380,9 @@ static void fill_result(const DevResult& r, u64 cells, gamdp_result& o)
 
 // ---- L0 batch -----------------------------------------------------------------------------------
 
-int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops)
+int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops)
 {
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return GAMDP_EHIP; }
-    const size_t n = tasks.size();
     if (n == 0) return 0;
     // reverse complements needed by this batch
     {
@@ -399,7 +391,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
             for (auto& p : need) if (p.first == s) { p.second.push_back(id); return; }
             need.push_back({s, {id}});
         };
-        for (const ITask& t : tasks) {
+        for (size_t ti = 0; ti < n; ti++) {
+            const ITask& t = tasks[ti];
             if (t.band > GAMDP_MAX_BAND) { set_error("band " + std::to_string(t.band) + " exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
             if (t.a_id >= t.sa->lens.size() || t.b_id >= t.sb->lens.size()) { set_error("sequence id out of range"); return GAMDP_EINVAL; }
             if ((t.a_rc && !t.sa->has_codes()) || (t.b_rc && !t.sb->has_codes())) { set_error("reverse complement requested on a packed-only (synthetic) sequence set"); return GAMDP_EINVAL; }
@@ -413,8 +406,11 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
     static const bool diag_timing = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    std::vector<Prepared> prep(n);
-    std::vector<int> prep_status(n);
+    // per-batch work arrays live in the context: a fresh 50 MB vector per call costs more in page faults than the
+    // preparation itself
+    if (w_prep.size() < n) { w_prep.resize(n); w_status.resize(n); w_key.resize(n); }
+    std::vector<Prepared>& prep = w_prep;
+    std::vector<int>& prep_status = w_status;
     // validation + descriptor of every task: independent per task, spread over host threads for big batches
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) prep_status[i] = prepare_task(tasks[i], prep[i]); });
     std::vector<std::vector<u32>> groups(K_COUNT);
@@ -466,8 +462,8 @@ int Ctx::align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_o
         cap_pinned = want;
     }
     u64 n_host_tasks = 0;
-    std::vector<u64> cells_key(n);
-    for (size_t i = 0; i < n; i++) cells_key[i] = prep[i].cells;
+    std::vector<u64>& cells_key = w_key;
+    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; };
     std::vector<Launch> launches;
     const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(0);
@@ -670,7 +666,8 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     const SeqSet* sa = reinterpret_cast<const SeqSet*>(set_a);
     const SeqSet* sb = reinterpret_cast<const SeqSet*>(set_b);
-    std::vector<ITask> it(n);
+    if (c->w_tasks.size() < n) c->w_tasks.resize(n);
+    std::vector<ITask>& it = c->w_tasks;
     parallel_for(n, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
             const gamdp_task& t = tasks[i];
@@ -678,7 +675,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
                           t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
         }
     });
-    return c->align(it, out, ops);
+    return c->align(it.data(), n, out, ops);
 }
 
 void gamdp_encode(const char* chars, uint64_t n, uint8_t* codes)

@@ -51,6 +51,14 @@ struct ITask {
     u64 begin_a, end_a, begin_b, end_b;
 };
 
+// a validated task: device descriptor + what the launch planner needs
+struct Prepared {
+    DevTask dt;
+    int kid;
+    u64 cells;
+    u64 dir_words;
+};
+
 struct Ctx {
     int device = -1;
     int n_cu = 0;
@@ -72,7 +80,14 @@ struct Ctx {
 
     void set_error(const std::string& s) { err = s; }
     int init(int dev);
-    int align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops);
+    // work arrays of align(), kept between calls
+    std::vector<Prepared> w_prep;
+    std::vector<int> w_status;
+    std::vector<u64> w_key;
+    std::vector<ITask> w_tasks;
+
+    int align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops);
+    int align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops) { return align(tasks.data(), tasks.size(), out, ops); }
     ~Ctx();
 };
 
