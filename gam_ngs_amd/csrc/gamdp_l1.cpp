@@ -51,17 +51,35 @@ void find_hits(const uint8_t* a, u64 alen, u64 a_start, u64 a_end, const uint8_t
             code = 4 * (code - top * s[p]) + s[p + word];
         }
     };
-    std::vector<std::pair<u64, u32>> idx;
-    idx.reserve(a_end - word + 2 - a_start);
-    roll(a, a_start, a_end - word + 1, [&](u64 code, u64 p) { idx.push_back({code, (u32)p}); });
-    std::sort(idx.begin(), idx.end());  // per code: positions ascending, like the reference's lists
+    // index of the a k-mers: open-addressing table code -> chain of positions (the reference keeps a std::map of
+    // position lists, ablast.hpp:61-69; only the multiset of (code, position) pairs matters for the vote)
+    const u64 n_a = a_end - word + 2 - a_start;
+    u64 cap = 16;
+    while (cap < 2 * n_a) cap *= 2;
+    static thread_local std::vector<u64> keys;
+    static thread_local std::vector<u32> head, next;
+    keys.assign(cap, 0);
+    head.assign(cap, 0);  // 0 = empty slot, else 1 + index of the newest position in the chain
+    next.assign(n_a, 0);
+    const u64 mask = cap - 1;
+    auto slot_of = [&](u64 code) {
+        u64 h = (code * 0x9E3779B97F4A7C15ull) >> 17 & mask;
+        while (head[h] != 0 && keys[h] != code) h = (h + 1) & mask;
+        return h;
+    };
+    roll(a, a_start, a_end - word + 1, [&](u64 code, u64 p) {
+        const u64 h = slot_of(code);
+        const u32 me = (u32)(p - a_start);
+        keys[h] = code;
+        next[me] = head[h];
+        head[h] = me + 1;
+    });
 
     std::vector<u64> f(a_end - a_start + 1, 0);
     roll(b, b_start, b_end - word + 1, [&](u64 code, u64 bp) {
-        auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(code, (u32)0));
         const u64 ib = bp - b_start;
-        for (; it != idx.end() && it->first == code; ++it) {
-            const u64 ia = it->second - a_start;
+        for (u32 e = head[slot_of(code)]; e != 0; e = next[e - 1]) {
+            const u64 ia = e - 1;
             if (ia >= ib) f[ia - ib]++;  // mark_found, ablast.hpp:71-78
         }
     });
