@@ -105,9 +105,9 @@ struct Tk {
 // otherwise idle, so this takes the work off the vector ALU.
 //   ring A: entry k = one-hot (bytes for dot4, nibbles for dot8) of a[A0 + k], A0 = a_base + begin_a - band; lane l needs
 //           k = tau + (C-1)*(l+1) at row-time tau.  With 17 columns per lane it is stored transposed,
-//           pos = (k%16)*128 + (k/16)%128, so the 64 lanes of a read (k = k0 + 16*l) hit 64 consecutive dwords (no
+//           pos = (k%16)*72 + (k/16)%72, so the 64 lanes of a read (k = k0 + 16*l) hit 64 consecutive dwords (no
 //           bank conflict) and the 16 rows of a block are 16 compile-time offsets from one per-lane address.
-//   ring B: entry k = score row(s) of b[b_base + begin_b + k]; lane l needs k = tau - l.  128 entries + a copy
+//   ring B: entry k = score row of b[b_base + begin_b + k]; lane l needs k = tau - l.  128 entries + a copy
 //           of the first 16 behind them so that the 16 rows of a block never wrap.
 //   (Kernels with fewer columns per lane -- lane stride C-1 not a multiple of 16 -- use the same rings with a
 //   plain layout pos = k % size plus a 16-entry copy behind the ring; their ring-A reads are 2..8-way bank
