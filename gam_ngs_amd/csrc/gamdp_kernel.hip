@@ -228,6 +228,54 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 
     int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
     const u32 tagK = (CE >= 0 && CE < C - 1 && lane == LE) ? 0x80000001u : 1u;
+#ifdef GAMDP_EXPERIMENT_DIRFREE
+    // FEASIBILITY EXPERIMENT (never part of the product build, results are NOT usable: nothing can be traced back):
+    // what the fill costs when a fast block keeps no per-cell direction -- 2 instructions per cell (v_dot4 + v_max3
+    // on untagged values) -- and instead stores what a later strip recomputation would need: the live row every 4th
+    // block and, every row-time, the two values crossing every 4th lane boundary.  See DESIGN.md, roadmap.
+    if (MODE == M_FAST && !HASN) {
+        const u32 killK = (CE >= 0 && CE < C - 1 && lane == LE) ? 0x80000000u : 0u;
+        gptr blkp = t.dir + (u64)blk * (u64)(C * 64);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
+            const u32 brow = ringB_lane[r] - 0x02020202u;  // no tag on the diag step
+            int L = Lin, x = NEG;
+            auto cell = [&](const int c) __attribute__((always_inline)) {
+                const int D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
+                int Uc = (c < C - 1) ? Lp[(c < C - 1) ? c + 1 : c] : x;
+                if (CE >= 0 && c == CE && CE < C - 1) Uc = (int)((u32)Uc | killK);
+                L = imax3(D, Uc, L);
+                Lp[c] = L;
+            };
+            cell(0);
+            x = wave_shl1(xkeep, Lp[0]);
+            xkeep = x;
+#pragma unroll
+            for (int c = 1; c < C; ++c) cell(c);
+            const int Lrecv = Lin;
+            Lin = wave_shr1(Lin, L);
+            if ((blk & 3) != 0 && (lane & 3) == 0) {  // boundary values of this row-time, 8 B per lane group
+                blkp[(r * 16 + (lane >> 2)) * 2] = (u32)Lrecv;
+                blkp[(r * 16 + (lane >> 2)) * 2 + 1] = (u32)Lp[0];
+            }
+        }
+        Lout = Lin;
+        if ((blk & 3) == 0) {  // live row of every lane, once per 4 blocks
+            constexpr int G = C / 4, REM = C % 4;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                u32x4 v = {(u32)Lp[4 * g], (u32)Lp[4 * g + 1], (u32)Lp[4 * g + 2], (u32)Lp[4 * g + 3]};
+                *(g4ptr)(blkp + g * 256 + lane * 4) = v;
+            }
+#pragma unroll
+            for (int e = 0; e < REM; ++e) blkp[G * 256 + lane * REM + e] = (u32)Lp[4 * G + e];
+        }
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) W[k] = W[k + ROWS];
+        return;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
