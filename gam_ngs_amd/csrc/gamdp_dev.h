@@ -41,7 +41,9 @@ struct DevTask {
 };
 
 enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4,
-             TF_DIAG_SKIP_TRACEBACK = 8 /* timing diagnostics only (GAMDP_DIAG_SKIP_TRACEBACK=1): results invalid */ };
+             TF_DIAG_SKIP_TRACEBACK = 8 /* timing diagnostics only (GAMDP_DIAG_SKIP_TRACEBACK=1): results invalid */,
+             TF_NO_DIRFREE = 16 /* GAMDP_DIAG_NO_DIRFREE=1: keep directions in every block (A/B measurements) */,
+             TF_DIAG_COUNT_MAT = 32 /* GAMDP_DIAG_COUNT_MAT=1: n_match := number of materialise() calls (results invalid) */ };
 
 struct DevResult {
     int32_t begin_a, begin_b;
@@ -62,6 +64,8 @@ struct LaunchParams {
     u64 slot_words;        // u32 words per slot
     u64 dir_words;         // direction words at the start of a slot; side buffers follow
     u32 ypad;              // side-buffer stride in words (>= 2*band+2)
+    u64 ckpt_off;          // word offsets inside a slot of the direction-free fill's row / boundary stores
+    u64 bnd_off;           // (0 = this launch keeps directions everywhere)
 };
 
 // Kernel variants.  C = band columns per lane; CE = (2*band) % C is the in-lane position of the

@@ -404,6 +404,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
 
     static const bool diag_skip_tb = std::getenv("GAMDP_DIAG_SKIP_TRACEBACK") != nullptr;
     static const bool diag_timing = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
+    static const bool diag_no_dirfree = std::getenv("GAMDP_DIAG_NO_DIRFREE") != nullptr;
+    static const bool diag_count_mat = std::getenv("GAMDP_DIAG_COUNT_MAT") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     // per-batch work arrays live in the context: a fresh 50 MB vector per call costs more in page faults than the
@@ -425,6 +427,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         }
         prep[i].dt.res_idx = (u32)i;
         if (diag_skip_tb) prep[i].dt.flags |= TF_DIAG_SKIP_TRACEBACK;
+        if (diag_no_dirfree) prep[i].dt.flags |= TF_NO_DIRFREE;
+        if (diag_count_mat) prep[i].dt.flags |= TF_DIAG_COUNT_MAT;
         if (ops && ops->ops_buf && ops->ops_cap[i] > 0) {
             prep[i].dt.flags |= TF_WANT_OPS;
             prep[i].dt.ops_off = ops_total;
@@ -464,7 +468,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     u64 n_host_tasks = 0;
     std::vector<u64>& cells_key = w_key;
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
-    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; };
+    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; u64 ckpt_off, bnd_off; };
     std::vector<Launch> launches;
     const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(0);
     for (int kid = 0; kid < K_COUNT; kid++) {
@@ -486,7 +490,15 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             }
             const u32 ypad = ((2 * maxband + 2 + 63) / 64) * 64;
             const u64 dirw = ((maxdir + 63) / 64) * 64;
-            const u64 slotw = dirw + 4ull * ypad;
+            // the tuned N-free kernels fill their fast blocks without directions and keep, per 4 blocks, one live row
+            // (C*64 words) and, per block, 512 boundary words instead (gamdp_kernel.hip, do_block_df)
+            u64 ckpt_words = 0, bnd_words = 0;
+            if (kid == K_C17_CE4) {
+                const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
+                ckpt_words = (nblk / 4 + 2) * cw;
+                bnd_words = (nblk + 4) * 512;
+            }
+            const u64 slotw = dirw + 4ull * ypad + ckpt_words + bnd_words;
             const u64 fit = arena_limit / (slotw * sizeof(u32));
             if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
             const u64 want = std::min<u64>(cur.size(), max_resident);
@@ -503,6 +515,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)cur.size();
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
             L.n_slots = (u32)std::min<u64>(want, fit);
+            L.ckpt_off = ckpt_words ? dirw + 4ull * ypad : 0;
+            L.bnd_off = L.ckpt_off + ckpt_words;
             {
                 DevTask* dst = h_tasks + n_host_tasks;
                 parallel_for(cur.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) dst[k] = prep[cur[k]].dt; });
@@ -544,6 +558,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.tasks = d_tasks + L.first; p.n_tasks = L.count; p.cursor = d_cursor + li;
             p.results = d_results; p.ops_buf = d_ops;
             p.scratch = d_scratch; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
+            p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
             HIPCHK(this, hipEventRecord(events[li].first, stream));
             const int e = launch_align(L.kid, p, L.n_slots, stream);
             if (e != 0) { set_error(std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)e)); return GAMDP_EHIP; }

@@ -94,6 +94,10 @@ struct Tk {
     int eaRel;    // end_a - begin_a + band clamped to int: band column of pos==end_a in row 0
     gptr dir;
     giptr h0row, pos0, lastrow, adh;
+    // direction-free fill: blocks [df_lo, df_hi) (multiples of 4) keep no directions; instead the live row of every
+    // 4th block start goes to ckpt and the values crossing every 4th lane boundary to bnd (see do_block_df)
+    gptr ckpt, bnd;
+    int df_lo, df_hi;
 };
 
 
@@ -197,6 +201,7 @@ __device__ __forceinline__ Tk load_uniform(const Tk* tp)
     t.fs = uni(t.fs) != 0; t.fe = uni(t.fe) != 0;
     t.iA = uni(t.iA); t.eaRel = uni(t.eaRel);
     t.dir = unip(t.dir); t.h0row = unip(t.h0row); t.pos0 = unip(t.pos0); t.lastrow = unip(t.lastrow); t.adh = unip(t.adh);
+    t.ckpt = unip(t.ckpt); t.bnd = unip(t.bnd); t.df_lo = uni(t.df_lo); t.df_hi = uni(t.df_hi);
     return t;
 }
 
@@ -214,6 +219,10 @@ __device__ __forceinline__ u64 dir_index(int blk, int lane, int c)
 // MODE bit 1 (END): rows of the pos==end_a anti-diagonal and/or the last row are in the block (side captures).
 enum { M_FAST = 0, M_TOP = 1, M_END = 2, M_BOTH = 3 };
 
+// which kernel variants run their fast blocks without directions (do_block_df / materialise): the tuned, N-free ones
+template <int CE, int C, bool HASN>
+constexpr bool DIRFREE_OK = !HASN && CE >= 0 && CE < C - 1 && C - 1 <= 16 && C >= 9;  // (measured a loss with 5 columns per lane)
+
 template <int C, int CE, bool HASN, int MODE>
 __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t,
                                          const int blk, const int lane, const int LE, const int kill_c)
@@ -228,54 +237,6 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 
     int xkeep = NEG;  // lane 63's `up` hand-off source does not exist
     const u32 tagK = (CE >= 0 && CE < C - 1 && lane == LE) ? 0x80000001u : 1u;
-#ifdef GAMDP_EXPERIMENT_DIRFREE
-    // FEASIBILITY EXPERIMENT (never part of the product build, results are NOT usable: nothing can be traced back):
-    // what the fill costs when a fast block keeps no per-cell direction -- 2 instructions per cell (v_dot4 + v_max3
-    // on untagged values) -- and instead stores what a later strip recomputation would need: the live row every 4th
-    // block and, every row-time, the two values crossing every 4th lane boundary.  See DESIGN.md, roadmap.
-    if (MODE == M_FAST && !HASN) {
-        const u32 killK = (CE >= 0 && CE < C - 1 && lane == LE) ? 0x80000000u : 0u;
-        gptr blkp = t.dir + (u64)blk * (u64)(C * 64);
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
-            const u32 brow = ringB_lane[r] - 0x02020202u;  // no tag on the diag step
-            int L = Lin, x = NEG;
-            auto cell = [&](const int c) __attribute__((always_inline)) {
-                const int D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
-                int Uc = (c < C - 1) ? Lp[(c < C - 1) ? c + 1 : c] : x;
-                if (CE >= 0 && c == CE && CE < C - 1) Uc = (int)((u32)Uc | killK);
-                L = imax3(D, Uc, L);
-                Lp[c] = L;
-            };
-            cell(0);
-            x = wave_shl1(xkeep, Lp[0]);
-            xkeep = x;
-#pragma unroll
-            for (int c = 1; c < C; ++c) cell(c);
-            const int Lrecv = Lin;
-            Lin = wave_shr1(Lin, L);
-            if ((blk & 3) != 0 && (lane & 3) == 0) {  // boundary values of this row-time, 8 B per lane group
-                blkp[(r * 16 + (lane >> 2)) * 2] = (u32)Lrecv;
-                blkp[(r * 16 + (lane >> 2)) * 2 + 1] = (u32)Lp[0];
-            }
-        }
-        Lout = Lin;
-        if ((blk & 3) == 0) {  // live row of every lane, once per 4 blocks
-            constexpr int G = C / 4, REM = C % 4;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                u32x4 v = {(u32)Lp[4 * g], (u32)Lp[4 * g + 1], (u32)Lp[4 * g + 2], (u32)Lp[4 * g + 3]};
-                *(g4ptr)(blkp + g * 256 + lane * 4) = v;
-            }
-#pragma unroll
-            for (int e = 0; e < REM; ++e) blkp[G * 256 + lane * REM + e] = (u32)Lp[4 * G + e];
-        }
-#pragma unroll
-        for (int k = 0; k < C - 1; ++k) W[k] = W[k + ROWS];
-        return;
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
@@ -392,6 +353,64 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
     for (int k = 0; k < C - 1; ++k) W[k] = W[k + ROWS];
 }
 
+// ---- a fast block that keeps no directions ------------------------------------------------------------------
+// The traceback reads the directions of the cells on the path only, so the fast blocks of the tuned kernels compute
+// plain values -- v_dot4 + v_max3 per cell, no tag, no direction word -- and store what materialise() below needs to
+// re-enact a 4-lane strip of the sweep later, with directions, around the path:
+//   ckpt: at the start of every 4th block (a "group" = 64 row-times) the live row of every lane;
+//   bnd:  every row-time, for every 4th lane, the chain value it received from its left neighbour and the value it
+//         hands to that neighbour (its new column 0): [block][row-time 16][lane/4 16][2], 128 B per row-time.
+// Values stay multiples of 4 (what the tagged blocks keep after stripping), so fast and slow blocks mix freely.
+template <int C, int CE>
+__device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t, const int blk, const int lane, const int LE)
+{
+    static_assert(CE >= 0 && CE < C - 1, "tuned kernels only");
+    const int tau0 = blk * ROWS;
+    const u32* ringA_lane;
+    if (RingA<C>::transposed) ringA_lane = s_ringA + (u32)((tau0 + (C - 1) * (lane + 1)) >> 4) % (u32)RingA<C>::COLS;
+    else ringA_lane = s_ringA + ((tau0 + (C - 1) * (lane + 1)) & (RingA<C>::size - 1));
+    const u32* ringB_lane = s_ringB + ((tau0 - lane) & (RING_B - 1));
+    if ((blk & 3) == 0) {
+        constexpr int G = C / 4, REM = C % 4;
+        gptr ck = t.ckpt + (u64)(blk >> 2) * (u64)(C * 64);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            u32x4 v = {(u32)Lp[4 * g], (u32)Lp[4 * g + 1], (u32)Lp[4 * g + 2], (u32)Lp[4 * g + 3]};
+            *(g4ptr)(ck + g * 256 + lane * 4) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < REM; ++e) ck[G * 256 + lane * REM + e] = (u32)Lp[4 * G + e];
+    }
+    gptr bp = t.bnd + (u64)blk * 512u + (u32)(lane >> 2) * 2u;
+    const bool edge = (lane & 3) == 0;
+    const u32 killK = (lane == LE) ? 0x80000000u : 0u;  // the last band column has no `up` source
+    int xkeep = NEG;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
+        const u32 brow = ringB_lane[r] - 0x02020202u;  // the ring holds the tagged table
+        const int Lrecv = Lin;
+        int L = Lin, x = NEG;
+        auto cell = [&](const int c) __attribute__((always_inline)) {
+            const int D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
+            int Uc = (c < C - 1) ? Lp[(c < C - 1) ? c + 1 : c] : x;
+            if (c == CE) Uc = (int)((u32)Uc | killK);
+            L = imax3(D, Uc, L);
+            Lp[c] = L;
+        };
+        cell(0);
+        x = wave_shl1(xkeep, Lp[0]);
+        xkeep = x;
+        if (edge) { bp[r * 32] = (u32)Lrecv; bp[r * 32 + 1] = (u32)Lp[0]; }
+#pragma unroll
+        for (int c = 1; c < C; ++c) cell(c);
+        Lout = L;
+        Lin = wave_shr1(Lin, L);
+    }
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k) W[k] = W[k + ROWS];
+}
+
 template <int C>
 struct BlockState {
     int Lp[C];
@@ -454,7 +473,7 @@ __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const i
 }
 
 // blocks [blk_begin, blk_end) are all "fast": every lane is past row 0, no pos <= 0 cell, no capture row
-template <int C, int CE, bool HASN>
+template <int C, int CE, bool HASN, bool DF>
 __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const int blk_begin_, const int blk_end_, const int lane)
 {
     const Tk t = load_uniform(tp);
@@ -501,17 +520,124 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
         }
         ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
                               __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
-        do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
+        if constexpr (DF) do_block_df<C, CE>(Lp, W, Lin, Lout, t, blk, lane, LE);
+        else do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
         a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
         if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
     }
     store_state<C>(st, Lp, acc, W, Lin, Lout);
 }
 
+// ---- directions of a 4-lane strip, on demand --------------------------------------------------------------
+// Re-enacts lanes 4q..4q+3 of the sweep over 16 groups (64 row-times each) at once -- lanes 4k..4k+3 of this
+// wavefront do group g_hi-k -- from what do_block_df stored, this time with the tagged cell, and writes the direction
+// words of those lanes exactly where the tagged fill would have put them.  The walk in finish_task calls it when it
+// enters direction-free blocks whose strip is not there yet; an alignment path drifts sideways only by its net indel
+// count, so nearly every call serves 1 000 rows of path.
+template <int C, int CE>
+__device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g_hi_, const int lane)
+{
+    static_assert(CE >= 0 && CE < C - 1 && C - 1 <= 16, "tuned kernels only");
+    constexpr int HR = 8;  // row-times per unrolled chunk
+    const Tk t = load_uniform(tp);
+    const int q = uni(q_), g_hi = uni(g_hi_);
+    const int lam = lane & 3;
+    const int R = 4 * q + lam;  // the lane of the fill this lane re-enacts
+    const int g_first = t.df_lo >> 2;
+    const int g = g_hi - (lane >> 2);
+    const bool live = g >= g_first;
+    const int gg = live ? g : g_first;  // lanes beyond the range redo the first group and store nothing
+    const int LE = (t.Y - 1) / C;
+
+    int Lp[C];
+    u32 acc[C];
+    u32 W[C - 1 + HR];
+    u32 sv[HR];
+    {
+        constexpr int G = C / 4, REM = C % 4;
+        gptr ck = t.ckpt + (u64)gg * (u64)(C * 64);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const u32x4 v = *(g4ptr)(ck + k * 256 + R * 4);
+            Lp[4 * k] = (int)v.x; Lp[4 * k + 1] = (int)v.y; Lp[4 * k + 2] = (int)v.z; Lp[4 * k + 3] = (int)v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < REM; ++e) Lp[4 * G + e] = (int)ck[G * 256 + R * REM + e];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0;
+    }
+    // quad shifts: lane lam <- lam-1 / lam+1 of the same strip (the strip's outer lanes take the stored values)
+    auto from_left = [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0x90, 0xf, 0xf, false); };   // quad_perm:[0,0,1,2]
+    auto from_right = [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0xF9, 0xf, 0xf, false); };  // quad_perm:[1,2,3,3]
+    int Lin = from_left(Lp[C - 1]);  // what the left neighbour handed over at the end of the previous row-time
+    const int tau_g = gg * 64;
+    const int64_t iaW = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * R + tau_g;  // W[k] <-> a[iaW + k]
+    {
+        const u32 aw = fetch16(t.a2, iaW);
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) W[k] = 1u << (((aw >> (2 * k)) & 3u) * 8u);
+    }
+    const u32 tagK = (R == LE) ? 0x80000001u : 1u;
+    // the stored boundary values this lane consumes: lam 0 the chain value entering the strip from the left, lam 3 the
+    // `up` hand-off entering from the right (none right of lane 63); lam 1, 2 load the left one and ignore it
+    const bool right_edge = lam == 3;
+    const bool has_right = q < 15;
+    gptr sp = t.bnd + (u64)gg * 2048u + (u32)((right_edge && has_right) ? (q + 1) * 2 + 1 : q * 2);
+#pragma unroll
+    for (int r = 0; r < HR; ++r) sv[r] = sp[r * 32];
+
+    // packed words of the chunk after the current one are requested a chunk ahead (nothing here waits on a load it
+    // has just issued)
+    const int64_t ia_new = iaW + (C - 1), ib_new = t.b_base + t.begin_b + tau_g - R;
+    u32 an_nx = fetch16(t.a2, ia_new), bw_nx = fetch16(t.b2, ib_new);
+    for (int ch = 0; ch < 64 / HR; ++ch) {
+        const u32 an = an_nx, bw = bw_nx;
+        const int nx = min(ch + 1, 64 / HR - 1) * HR;  // the last chunk re-reads itself
+        an_nx = fetch16(t.a2, ia_new + nx);
+        bw_nx = fetch16(t.b2, ib_new + nx);
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            W[C - 1 + r] = 1u << (((an >> (2 * r)) & 3u) * 8u);
+            const u32 brow = 0x32323232u + (0x24u << (((bw >> (2 * r)) & 3u) * 8u));
+            const int s = (int)sv[r];
+            sv[r] = sp[(nx + r) * 32];  // same row of the next chunk: in flight while this chunk computes
+            int L = (lam == 0) ? s : Lin;
+            int x = NEG;
+            auto cell = [&](const int c) __attribute__((always_inline)) {
+                const int D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
+                const int Uc = (c < C - 1) ? (int)((u32)Lp[(c < C - 1) ? c + 1 : c] | ((c == CE) ? tagK : 1u)) : (x | 1);
+                const int Rv = imax3(D, Uc, L);
+                acc[c] = __builtin_amdgcn_alignbit((u32)Rv, acc[c], 2);
+                L = Rv & ~3;
+                Lp[c] = L;
+            };
+            cell(0);
+            x = from_right(Lp[0]);
+            if (right_edge) x = has_right ? s : NEG;
+#pragma unroll
+            for (int c = 1; c < C; ++c) cell(c);
+            Lin = from_left(L);
+        }
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) W[k] = W[k + HR];
+        if ((ch & 1) && live) {
+            constexpr int G = C / 4, REM = C % 4;
+            gptr blkp = t.dir + (u64)(gg * 4 + (ch >> 1)) * (u64)(C * 64);
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                u32x4 v = {acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
+                *(g4ptr)(blkp + k * 256 + R * 4) = v;
+            }
+#pragma unroll
+            for (int e = 0; e < REM; ++e) blkp[G * 256 + R * REM + e] = acc[4 * G + e];
+        }
+    }
+}
+
 // ---- phases C + D: end-cell search and traceback ------------------------------------------------------
 // Kept out of line (like the slow block) so that its registers -- and the scalar registers holding its many
 // compare masks -- are allocated separately from the hot fill loop.
-template <int C, bool HASN>
+template <int C, int CE, bool HASN>
 __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, const LaunchParams* pp, const int lane)
 {
     const Tk t = load_uniform(tp);
@@ -614,11 +740,39 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                 const u32 lo = (u32)__builtin_amdgcn_readlane((int)v, k), hi = (u32)__builtin_amdgcn_readlane((int)v, k - 1);
                 return __builtin_amdgcn_alignbit(hi, lo, (u32)(idx & 15) * 2u);
             };
+            // strip of direction-free blocks whose directions materialise() has produced: lanes 4*mat_q .. +3, blocks
+            // mat_lo .. mat_hi
+            int mat_q = -1, mat_lo = 0, mat_hi = -1, mat_calls = 0;
+            long long mat_ticks = 0;
+            int dg_iters = 0, dg_refills = 0;
+            const long long walk_t0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
+            int cvalid_lo = 0;  // cached blocks below this one are not usable (direction-free, not materialised)
             auto get_word = [&](const int blk, const int l_, const int c_) -> u32 {
                 constexpr int G = C / 4;
                 const int g = c_ >> 2;
                 int k = cblk0 - blk;
-                if (l_ != cl || g != cg || k < 0 || k >= TB_DEPTH) {
+                if (l_ != cl || g != cg || k < 0 || k >= TB_DEPTH || blk < cvalid_lo) {
+                    cvalid_lo = 0;
+                    dg_refills++;
+                    if constexpr (DIRFREE_OK<CE, C, HASN>) {
+                        if (blk >= t.df_hi) {
+                            cvalid_lo = t.df_hi;  // the refill may reach down into direction-free blocks: not usable
+                        } else if (blk >= t.df_lo) {
+                            if (!((l_ >> 2) == mat_q && blk >= mat_lo && blk <= mat_hi)) {
+                                const int g_hi = blk >> 2;
+                                const long long tm0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
+                                materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0)>(tp, l_ >> 2, g_hi, lane);
+                                if (dt_flags & TF_DIAG_COUNT_MAT) mat_ticks += wall_clock64() - tm0;
+                                // the loads below must see those stores: wait until L2 has them, then drop this CU's L1
+                                // lines (an agent-scope release would write back the whole L2 of the XCD, far too much)
+                                __builtin_amdgcn_s_waitcnt(0);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                mat_q = l_ >> 2; mat_hi = 4 * g_hi + 3; mat_lo = max(4 * (g_hi - 15), t.df_lo);
+                                mat_calls++;
+                            }
+                            cvalid_lo = (mat_lo == t.df_lo) ? 0 : mat_lo;  // below df_lo the tagged blocks are all there
+                        }
+                    }
                     cblk0 = blk; cl = l_; cg = g; k = 0;
                     // no lane-dependent branch here (it would make the compiler treat the whole walk as
                     // divergent): lanes >= TB_DEPTH and blocks below 0 just re-read a neighbour's address
@@ -641,7 +795,9 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                 // the walk state is wave-uniform by construction; pin it to scalar registers every iteration so
                 // the body is selected as SALU code whatever the divergence analysis concluded about the loop
                 x = uni(x); y = uni(y); pos = uni(pos); l = uni(l); c = uni(c);
+                dg_iters = uni(dg_iters) + 1; dg_refills = uni(dg_refills);
                 cblk0 = uni(cblk0); cl = uni(cl); cg = uni(cg);
+                mat_q = uni(mat_q); mat_lo = uni(mat_lo); mat_hi = uni(mat_hi); cvalid_lo = uni(cvalid_lo); mat_calls = uni(mat_calls);
                 sa_w0 = uni64(sa_w0); sb_w0 = uni64(sb_w0);
                 if (x == 0 || pos == 0 || want_ops) {
                     // single step with the reference's exact rules
@@ -743,6 +899,12 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
             res.last_a = have_last ? la : res.begin_a;
             res.last_b = have_last ? lb : res.begin_b;
             res.flags = (have_first ? 1u : 0u) | (have_last ? 2u : 0u) | (ST_OK << 8);
+            if (dt_flags & TF_DIAG_COUNT_MAT) {  // diagnostics only: result unusable
+                res.n_match = (u32)mat_calls;
+                res.first_a = (int)mat_ticks;
+                res.first_b = (int)(wall_clock64() - walk_t0);
+                res.last_a = dg_iters; res.last_b = dg_refills;
+            }
         }
     }
     if (lane == 0) p_results[dt_res_idx] = res;
@@ -846,6 +1008,9 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
     t.pos0 = t.h0row + p.ypad;
     t.lastrow = t.pos0 + p.ypad;
     t.adh = t.lastrow + p.ypad;
+    t.ckpt = (gptr)(slot + p.ckpt_off);
+    t.bnd = (gptr)(slot + p.bnd_off);
+    t.df_lo = t.df_hi = 0;
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
         t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
@@ -867,12 +1032,33 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
         const bool end = !((tau0 + ROWS - 1 < X - 1) && ((int64_t)(tau0 + ROWS - 1) < iE0 || (int64_t)(tau0 - LE) > iE1));
         return (top ? M_TOP : 0) | (end ? M_END : 0);
     };
+    if constexpr (DIRFREE_OK<CE, C, HASN>) {
+        // the first run of fast blocks goes direction-free, in whole groups of 4 blocks, leaving at least one tagged
+        // fast block in front (what a lane receives at a group start must be its neighbour's plain last column)
+        if (p.ckpt_off != 0 && !(dt.flags & TF_NO_DIRFREE)) {
+            int b0 = 0;
+            while (b0 < nblk && mode_of(b0) != M_FAST) ++b0;
+            int b1 = b0;
+            while (b1 < nblk && mode_of(b1) == M_FAST) ++b1;
+            const int lo = (b0 + 1 + 3) & ~3, hi = b1 & ~3;
+            if (hi - lo >= 8) { t.df_lo = lo; t.df_hi = hi; }
+        }
+    }
     for (int blk = 0; blk < nblk;) {
         const int m = mode_of(blk);
         if (m == M_FAST) {
             int e = blk + 1;
             while (e < nblk && mode_of(e) == M_FAST) ++e;
-            fast_range<C, CE, HASN>(&st, &t, blk, e, lane);
+            if constexpr (DIRFREE_OK<CE, C, HASN>) {
+                if (blk < t.df_hi && e > t.df_lo && t.df_hi > t.df_lo) {  // this is the run that holds the direction-free groups
+                    if (blk < t.df_lo) fast_range<C, CE, HASN, false>(&st, &t, blk, t.df_lo, lane);
+                    fast_range<C, CE, HASN, true>(&st, &t, t.df_lo, t.df_hi, lane);
+                    if (t.df_hi < e) fast_range<C, CE, HASN, false>(&st, &t, t.df_hi, e, lane);
+                    blk = e;
+                    continue;
+                }
+            }
+            fast_range<C, CE, HASN, false>(&st, &t, blk, e, lane);
             blk = e;
         } else {
             if (m == M_TOP) slow_block<C, CE, HASN, M_TOP>(&st, &t, blk, lane);
@@ -881,7 +1067,7 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
             ++blk;
         }
     }
-    finish_task<C, HASN>(&t, &dt, &p, lane);
+    finish_task<C, CE, HASN>(&t, &dt, &p, lane);
 }
 
 template <int C, int CE, bool HASN>

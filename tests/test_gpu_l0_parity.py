@@ -186,3 +186,41 @@ def test_n_aware_kernels_on_every_case_in_a_fresh_process():
                         "-k", "random_cases or medium_pairs or golden_large or row_cap"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_direction_free_fill_and_strip_materialisation():
+    """Band 512 without N runs its fast blocks direction-free and re-creates the directions of a 4-lane strip around
+    the path on demand (gamdp_kernel.hip: do_block_df / materialise).  Pairs built to stress that: indel-rich, with a
+    net drift of the path across many strips (insertions >> deletions and the reverse), windows that start deep inside
+    the sequences, force flags, a second fast run after an anti-diagonal in the middle; each with and without the edit
+    string, each also with the feature switched off in a child process."""
+    import os, subprocess, sys
+    import _cases
+    rng = random.Random(99)
+    cases = []
+    for n, sub, ins, dele in ((30000, 0.02, 0.03, 0.002), (30000, 0.02, 0.002, 0.03), (45000, 0.03, 0.02, 0.02),
+                              (12000, 0.0, 0.0, 0.0), (20000, 0.01, 0.04, 0.0005), (20000, 0.05, 0.01, 0.01)):
+        a = _cases.rand_seq(rng, n)
+        b = _cases.mutate(rng, a, sub, ins, dele)
+        cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    a = _cases.rand_seq(rng, 26000)
+    b = _cases.mutate(rng, a[3000:], 0.02, 0.01, 0.01)
+    cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=3000, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=True, fe=False))
+    cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=2800, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=True))
+    cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=3000, end_a=14000, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=3300, end_a=len(a) + 100, begin_b=100, end_b=20000, fs=False, fe=False))
+    n_ok = 0
+    for want_ops in (False, True):
+        res = run_cases(cases, want_ops=want_ops)
+        for k, (cs, r) in enumerate(zip(cases, res)):
+            o, ops = oracle_for(cs, want_ops)
+            assert r.key() == o.key(), (k, r.key(), o.key())
+            if want_ops:
+                assert r.ops == ops, k
+            n_ok += o.status == 0
+    assert n_ok >= 16
+    if not os.environ.get("GAMDP_DIAG_NO_DIRFREE"):
+        env = dict(os.environ, GAMDP_DIAG_NO_DIRFREE="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                            "direction_free or golden_large"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
