@@ -725,7 +725,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
             // (one 16 B load per lane, all in flight together) serves several dependent steps of the walk.
             constexpr int TB_DEPTH = 16;
             int cblk0 = -1, cl = -1, cg = -1;
-            u32 cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
+            u32 cw = 0;  // lane 4*k + e holds the direction word of block (cblk0 - k), column 4*cg + e
             // Packed-sequence window for the match counting: lane k holds 2-bit word (w0 - k); the walk moves towards
             // lower indices, so one refill (one coalesced 256 B load) covers the next ~1000 bases.
             int64_t sa_w0 = INT64_MIN, sb_w0 = INT64_MIN;
@@ -748,7 +748,6 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
             const long long walk_t0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
             int cvalid_lo = 0;  // cached blocks below this one are not usable (direction-free, not materialised)
             auto get_word = [&](const int blk, const int l_, const int c_) -> u32 {
-                constexpr int G = C / 4;
                 const int g = c_ >> 2;
                 int k = cblk0 - blk;
                 if (l_ != cl || g != cg || k < 0 || k >= TB_DEPTH || blk < cvalid_lo) {
@@ -774,30 +773,25 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         }
                     }
                     cblk0 = blk; cl = l_; cg = g; k = 0;
-                    // no lane-dependent branch here (it would make the compiler treat the whole walk as
-                    // divergent): lanes >= TB_DEPTH and blocks below 0 just re-read a neighbour's address
-                    const int myblk = max(blk - min(lane, TB_DEPTH - 1), 0);
-                    if (g < G) {
-                        const u32x4 v = *(g4ptr)(t.dir + dir_index<C>(myblk, l_, 4 * g));
-                        cv0 = v.x; cv1 = v.y; cv2 = v.z; cv3 = v.w;
-                    } else {
-                        cv0 = t.dir[dir_index<C>(myblk, l_, 4 * G)];
-                        if (C % 4 > 1) cv1 = t.dir[dir_index<C>(myblk, l_, (C % 4 > 1) ? 4 * G + 1 : 4 * G)];
-                        if (C % 4 > 2) cv2 = t.dir[dir_index<C>(myblk, l_, (C % 4 > 2) ? 4 * G + 2 : 4 * G)];
-                    }
+                    // one coalesced load: each group of 4 lanes reads the 16 B of one block.  No lane-dependent branch
+                    // (it would make the compiler treat the whole walk as divergent): blocks below 0 and columns past
+                    // the lane's last one just re-read a valid word
+                    const int myblk = max(blk - (lane >> 2), 0);
+                    const int myc = min(4 * g + (lane & 3), C - 1);
+                    cw = t.dir[dir_index<C>(myblk, l_, myc)];
                 }
-                const int e = c_ & 3;
-                const u32 sel = (e == 0) ? cv0 : (e == 1) ? cv1 : (e == 2) ? cv2 : cv3;
-                return (u32)__builtin_amdgcn_readlane((int)sel, __builtin_amdgcn_readfirstlane(k));
+                return (u32)__builtin_amdgcn_readlane((int)cw, __builtin_amdgcn_readfirstlane(4 * k + (c_ & 3)));
             };
             if (dt_flags & TF_DIAG_SKIP_TRACEBACK) x = -1;
             while (x >= 0 && y >= 0 && pos >= 0) {
                 // the walk state is wave-uniform by construction; pin it to scalar registers every iteration so
                 // the body is selected as SALU code whatever the divergence analysis concluded about the loop
                 x = uni(x); y = uni(y); pos = uni(pos); l = uni(l); c = uni(c);
-                dg_iters = uni(dg_iters) + 1; dg_refills = uni(dg_refills);
+#ifdef GAMDP_DIAG_COUNTERS
+                dg_iters = uni(dg_iters) + 1; dg_refills = uni(dg_refills); mat_calls = uni(mat_calls);
+#endif
                 cblk0 = uni(cblk0); cl = uni(cl); cg = uni(cg);
-                mat_q = uni(mat_q); mat_lo = uni(mat_lo); mat_hi = uni(mat_hi); cvalid_lo = uni(cvalid_lo); mat_calls = uni(mat_calls);
+                mat_q = uni(mat_q); mat_lo = uni(mat_lo); mat_hi = uni(mat_hi); cvalid_lo = uni(cvalid_lo);
                 sa_w0 = uni64(sa_w0); sb_w0 = uni64(sb_w0);
                 if (x == 0 || pos == 0 || want_ops) {
                     // single step with the reference's exact rules
@@ -846,6 +840,77 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         if (++c == C) { c = 0; l++; }
                     }
                     len++;
+                } else if constexpr (!HASN) {
+                    // interior: consume a whole run of diagonal steps in one go, with all 64 lanes: the lanes that hold
+                    // this column's words of the cached blocks find where the run ends (ballot), then 16 bases per
+                    // lane are compared straight out of the two packed-sequence windows.  A single wavefront issues
+                    // about one instruction per 4 cycles, so the walk is bound by its instruction count, not by the
+                    // vector ALU: one iteration per run instead of one per direction word.
+                    const int tau = x + l, blk = tau >> 4, r = tau & 15;
+                    const u32 w_here = get_word(blk, l, c);  // (re)fills the cache / materialises the strip if needed
+                    const int k0 = cblk0 - blk, e = c & 3;
+                    const int myk = lane >> 2;
+                    const bool mine = ((lane & 3) == e) && myk >= k0 && (cblk0 - myk) >= max(cvalid_lo, 0);
+                    u32 T = cw ^ 0xAAAAAAAAu;  // a diagonal step reads 00
+                    if (myk == k0) T <<= (30 - 2 * r);  // the block the walk stands in: row r on top
+                    const int avail = T ? (__builtin_clz(T) >> 1) : ((myk == k0) ? r + 1 : 16);
+                    const u64 m_mine = __ballot(mine), m_stop = __ballot(mine && T != 0u);
+                    int n;
+                    if (m_stop == 0) {
+                        n = (r + 1) + 16 * (((63 - __builtin_clzll(m_mine)) >> 2) - k0);
+                    } else {
+                        const int Ls = __builtin_ctzll(m_stop), ks = Ls >> 2;
+                        const int lead = __builtin_amdgcn_readlane(avail, Ls);
+                        n = (ks == k0) ? lead : (r + 1) + 16 * (ks - k0 - 1) + lead;
+                    }
+                    n = min(n, min(x, pos));  // stay in x >= 1, pos >= 1
+                    if (n > 0) {
+                        // chunk j (from the top of the run) = bases [hi - 16j - 15, hi - 16j] of both sequences
+                        const int64_t ia_hi = t.a_base + pos, ib_hi = t.b_base + t.begin_b + x;
+                        const int64_t wa = (ia_hi - 15) >> 4, wb = (ib_hi - 15) >> 4;
+                        const int64_t wa_bot = (ia_hi - n - 15) >> 4, wb_bot = (ib_hi - n - 15) >> 4;
+                        if (wa + 1 > sa_w0 || wa_bot < sa_w0 - 63) { sa_w0 = wa + 1; sa_v = t.a2[sa_w0 - lane]; }
+                        if (wb + 1 > sb_w0 || wb_bot < sb_w0 - 63) { sb_w0 = wb + 1; sb_v = t.b2[sb_w0 - lane]; }
+                        const int da = (int)(sa_w0 - wa), db = (int)(sb_w0 - wb);  // lane of chunk 0's low word (>= 1)
+                        const u32 a16 = __builtin_amdgcn_alignbit((u32)wave_shr1(0, (int)sa_v), sa_v, (u32)((ia_hi - 15) & 15) * 2u);
+                        const u32 b16s = __builtin_amdgcn_alignbit((u32)wave_shr1(0, (int)sb_v), sb_v, (u32)((ib_hi - 15) & 15) * 2u);
+                        const u32 b16 = (u32)__builtin_amdgcn_ds_bpermute(4 * (lane + db - da), (int)b16s);
+                        const int j = lane - da;
+                        const u32 xr = a16 ^ b16;
+                        const u32 ne = (xr | (xr >> 1)) & 0x55555555u;  // bit 2p set: bases p differ
+                        const int p0 = 16 * j + 16 - n;                 // first base of the chunk that still belongs to the run
+                        u32 msk = (p0 <= 0) ? 0x55555555u : ((p0 >= 16) ? 0u : (0x55555555u << (2 * p0)));
+                        if (j < 0) msk = 0u;
+                        u32 eq = ~ne & msk;
+                        const u64 m_eq = __ballot(eq != 0u);
+                        if (m_eq) {
+                            // sum over the wavefront with DPP adds (a butterfly through ds_bpermute costs six LDS round trips)
+                            int cnt = __builtin_popcount(eq);
+                            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+                            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+                            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);  // row_half_mirror
+                            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);  // row_mirror: every lane = its row's sum
+                            nm += (u32)(__builtin_amdgcn_readlane(cnt, 0) + __builtin_amdgcn_readlane(cnt, 16) +
+                                        __builtin_amdgcn_readlane(cnt, 32) + __builtin_amdgcn_readlane(cnt, 48));
+                            const int Ltop = __builtin_ctzll(m_eq), Lbot = 63 - __builtin_clzll(m_eq);
+                            const u32 eq_top = (u32)__builtin_amdgcn_readlane((int)eq, Ltop), eq_bot = (u32)__builtin_amdgcn_readlane((int)eq, Lbot);
+                            const int off_hi = 16 * (Ltop - da) + 15 - ((31 - __builtin_clz(eq_top)) >> 1);  // steps below the top of the run
+                            const int off_lo = 16 * (Lbot - da) + 15 - (__builtin_ctz(eq_bot) >> 1);
+                            if (!have_last) { have_last = true; la = pos - off_hi; lb = t.begin_b + x - off_hi; }
+                            have_first = true; fa = pos - off_lo; fb = t.begin_b + x - off_lo;
+                        }
+                        x -= n; pos -= n; len += (u32)n;
+                    } else {
+                        const u32 tag = (w_here >> (r * 2)) & 3u;
+                        if (tag == 1u) {  // GAP_A
+                            x--; y++;
+                            if (++c == C) { c = 0; l++; }
+                        } else {  // GAP_B
+                            y--; pos--;
+                            if (--c < 0) { c = C - 1; l--; }
+                        }
+                        len++;
+                    }
                 } else {
                     // interior: consume a whole run of diagonal steps from one direction word
                     const int tau = x + l, blk = tau >> 4, r = tau & 15;
