@@ -359,7 +359,8 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 // re-enact a 4-lane strip of the sweep later, with directions, around the path:
 //   ckpt: at the start of every 4th block (a "group" = 64 row-times) the live row of every lane;
 //   bnd:  every row-time, for every 4th lane, the chain value it received from its left neighbour and the value it
-//         hands to that neighbour (its new column 0): [block][row-time 16][lane/4 16][2], 128 B per row-time.
+//         hands to that neighbour (its new column 0): [block][received | handed][lane/4 16][row-time 16], written 16 B
+//         (four row-times) at a time so that a strip later reads its 16 row-times of a block as one 64 B line.
 // Values stay multiples of 4 (what the tagged blocks keep after stripping), so fast and slow blocks mix freely.
 template <int C, int CE>
 __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t, const int blk, const int lane, const int LE)
@@ -381,8 +382,9 @@ __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int&
 #pragma unroll
         for (int e = 0; e < REM; ++e) ck[G * 256 + lane * REM + e] = (u32)Lp[4 * G + e];
     }
-    gptr bp = t.bnd + (u64)blk * 512u + (u32)(lane >> 2) * 2u;
+    gptr bp = t.bnd + (u64)blk * 512u + (u32)(lane >> 2) * 16u;  // [plane 2][lane/4 16][row-time 16]
     const bool edge = (lane & 3) == 0;
+    u32 keepL[4], keepP[4];  // four row-times of boundary values per 16 B store
     const u32 killK = (lane == LE) ? 0x80000000u : 0u;  // the last band column has no `up` source
     int xkeep = NEG;
 #pragma unroll
@@ -401,7 +403,13 @@ __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int&
         cell(0);
         x = wave_shl1(xkeep, Lp[0]);
         xkeep = x;
-        if (edge) { bp[r * 32] = (u32)Lrecv; bp[r * 32 + 1] = (u32)Lp[0]; }
+        keepL[r & 3] = (u32)Lrecv;
+        keepP[r & 3] = (u32)Lp[0];
+        if ((r & 3) == 3 && edge) {
+            const u32x4 vl = {keepL[0], keepL[1], keepL[2], keepL[3]}, vp = {keepP[0], keepP[1], keepP[2], keepP[3]};
+            *(g4ptr)(bp + (r - 3)) = vl;
+            *(g4ptr)(bp + 256 + (r - 3)) = vp;
+        }
 #pragma unroll
         for (int c = 1; c < C; ++c) cell(c);
         Lout = L;
@@ -582,9 +590,14 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
     // `up` hand-off entering from the right (none right of lane 63); lam 1, 2 load the left one and ignore it
     const bool right_edge = lam == 3;
     const bool has_right = q < 15;
-    gptr sp = t.bnd + (u64)gg * 2048u + (u32)((right_edge && has_right) ? (q + 1) * 2 + 1 : q * 2);
-#pragma unroll
-    for (int r = 0; r < HR; ++r) sv[r] = sp[r * 32];
+    gptr sp = t.bnd + (u64)gg * 2048u + (u32)((right_edge && has_right) ? 256 + (q + 1) * 16 : q * 16);
+    static_assert(HR == 8, "the stream is loaded 4 row-times (16 B) at a time");
+    auto load_stream4 = [&](const int chunk, const int half) {  // row-times 4*half .. +3 of a chunk
+        const u32x4 v = *(g4ptr)(sp + (u32)(chunk >> 1) * 512u + (u32)(chunk & 1) * 8u + (u32)half * 4u);
+        sv[4 * half] = v.x; sv[4 * half + 1] = v.y; sv[4 * half + 2] = v.z; sv[4 * half + 3] = v.w;
+    };
+    load_stream4(0, 0);
+    load_stream4(0, 1);
 
     // packed words of the chunk after the current one are requested a chunk ahead (nothing here waits on a load it
     // has just issued)
@@ -600,7 +613,6 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
             W[C - 1 + r] = 1u << (((an >> (2 * r)) & 3u) * 8u);
             const u32 brow = 0x32323232u + (0x24u << (((bw >> (2 * r)) & 3u) * 8u));
             const int s = (int)sv[r];
-            sv[r] = sp[(nx + r) * 32];  // same row of the next chunk: in flight while this chunk computes
             int L = (lam == 0) ? s : Lin;
             int x = NEG;
             auto cell = [&](const int c) __attribute__((always_inline)) {
@@ -617,9 +629,13 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
 #pragma unroll
             for (int c = 1; c < C; ++c) cell(c);
             Lin = from_left(L);
+            // the same rows of the next chunk: in flight while this chunk computes
+            if (r == 3) load_stream4(nx / HR, 0);
+            if (r == 7) load_stream4(nx / HR, 1);
         }
 #pragma unroll
         for (int k = 0; k < C - 1; ++k) W[k] = W[k + HR];
+#ifndef GAMDP_EXP_MAT_NOSTORE
         if ((ch & 1) && live) {
             constexpr int G = C / 4, REM = C % 4;
             gptr blkp = t.dir + (u64)(gg * 4 + (ch >> 1)) * (u64)(C * 64);
@@ -631,7 +647,11 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
 #pragma unroll
             for (int e = 0; e < REM; ++e) blkp[G * 256 + R * REM + e] = acc[4 * G + e];
         }
+#endif
     }
+#ifdef GAMDP_EXP_MAT_NOSTORE
+    if (acc[0] == 0x12345678u && live) t.dir[lane] = acc[1];  // keep the work alive
+#endif
 }
 
 // ---- phases C + D: end-cell search and traceback ------------------------------------------------------
@@ -782,7 +802,16 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                 }
                 return (u32)__builtin_amdgcn_readlane((int)cw, __builtin_amdgcn_readfirstlane(4 * k + (c_ & 3)));
             };
-            if (dt_flags & TF_DIAG_SKIP_TRACEBACK) x = -1;
+            if (dt_flags & TF_DIAG_SKIP_TRACEBACK) {
+                if constexpr (DIRFREE_OK<CE, C, HASN>) {
+                    // timing diagnostics: with GAMDP_DIAG_COUNT_MAT as well, do the strip materialisations a walk down
+                    // the middle of the band would ask for, and nothing else
+                    if (dt_flags & TF_DIAG_COUNT_MAT)
+                        for (int g_hi = (t.df_hi >> 2) - 1; g_hi >= (t.df_lo >> 2); g_hi -= 16)
+                            materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0)>(tp, (Y / 2) / (4 * C), g_hi, lane);
+                }
+                x = -1;
+            }
             while (x >= 0 && y >= 0 && pos >= 0) {
                 // the walk state is wave-uniform by construction; pin it to scalar registers every iteration so
                 // the body is selected as SALU code whatever the divergence analysis concluded about the loop
