@@ -884,14 +884,16 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                     if (myk == k0) T <<= (30 - 2 * r);  // the block the walk stands in: row r on top
                     const int avail = T ? (__builtin_clz(T) >> 1) : ((myk == k0) ? r + 1 : 16);
                     const u64 m_mine = __ballot(mine), m_stop = __ballot(mine && T != 0u);
-                    int n;
+                    int n, Ls = -1;
                     if (m_stop == 0) {
                         n = (r + 1) + 16 * (((63 - __builtin_clzll(m_mine)) >> 2) - k0);
                     } else {
-                        const int Ls = __builtin_ctzll(m_stop), ks = Ls >> 2;
+                        Ls = __builtin_ctzll(m_stop);
+                        const int ks = Ls >> 2;
                         const int lead = __builtin_amdgcn_readlane(avail, Ls);
                         n = (ks == k0) ? lead : (r + 1) + 16 * (ks - k0 - 1) + lead;
                     }
+                    const int n_run = n;
                     n = min(n, min(x, pos));  // stay in x >= 1, pos >= 1
                     if (n > 0) {
                         // chunk j (from the top of the run) = bases [hi - 16j - 15, hi - 16j] of both sequences
@@ -929,6 +931,19 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                             have_first = true; fa = pos - off_lo; fb = t.begin_b + x - off_lo;
                         }
                         x -= n; pos -= n; len += (u32)n;
+                        // the run ended at a gap whose direction word is in the cache: take that step right away
+                        if (Ls >= 0 && n == n_run && x >= 1 && pos >= 1) {
+                            const u32 w2 = (u32)__builtin_amdgcn_readlane((int)cw, Ls);
+                            const u32 tag2 = (w2 >> (((x + l) & 15) * 2)) & 3u;
+                            if (tag2 == 1u) {  // GAP_A
+                                x--; y++;
+                                if (++c == C) { c = 0; l++; }
+                            } else {  // GAP_B
+                                y--; pos--;
+                                if (--c < 0) { c = C - 1; l--; }
+                            }
+                            len++;
+                        }
                     } else {
                         const u32 tag = (w_here >> (r * 2)) & 3u;
                         if (tag == 1u) {  // GAP_A
