@@ -635,7 +635,6 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
         }
 #pragma unroll
         for (int k = 0; k < C - 1; ++k) W[k] = W[k + HR];
-#ifndef GAMDP_EXP_MAT_NOSTORE
         if ((ch & 1) && live) {
             constexpr int G = C / 4, REM = C % 4;
             gptr blkp = t.dir + (u64)(gg * 4 + (ch >> 1)) * (u64)(C * 64);
@@ -647,11 +646,7 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
 #pragma unroll
             for (int e = 0; e < REM; ++e) blkp[G * 256 + R * REM + e] = acc[4 * G + e];
         }
-#endif
     }
-#ifdef GAMDP_EXP_MAT_NOSTORE
-    if (acc[0] == 0x12345678u && live) t.dir[lane] = acc[1];  // keep the work alive
-#endif
 }
 
 // ---- phases C + D: end-cell search and traceback ------------------------------------------------------
