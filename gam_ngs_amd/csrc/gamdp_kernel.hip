@@ -221,7 +221,7 @@ enum { M_FAST = 0, M_TOP = 1, M_END = 2, M_BOTH = 3 };
 
 // which kernel variants run their fast blocks without directions (do_block_df / materialise): the tuned, N-free ones
 template <int CE, int C, bool HASN>
-constexpr bool DIRFREE_OK = !HASN && CE >= 0 && CE < C - 1 && C - 1 <= 16 && C >= 9;  // (measured a loss with 5 columns per lane)
+constexpr bool DIRFREE_OK = !HASN && CE >= 0 && CE < C - 1 && C - 1 <= 16 && C >= 9;  // (a loss with 5 columns per lane: 20-column strips, per-row work dominates)
 
 template <int C, int CE, bool HASN, int MODE>
 __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t,
