@@ -493,7 +493,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // the tuned N-free kernels fill their fast blocks without directions and keep, per 4 blocks, one live row
             // (C*64 words) and, per block, 512 boundary words instead (gamdp_kernel.hip, do_block_df)
             u64 ckpt_words = 0, bnd_words = 0;
-            if (kid == K_C17_CE4) {
+            if (kid == K_C17_CE4 || kid == K_C17_CE4_N) {
                 const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * cw;
                 bnd_words = (nblk + 4) * 512;

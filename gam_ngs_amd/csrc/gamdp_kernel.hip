@@ -152,16 +152,17 @@ template <bool HASN>
 __device__ __forceinline__ u32 enc_a(u32 code2, bool isn)
 {
     // N-aware: one-hot NIBBLE (value 4) per letter A T C G N + a constant 10 in nibble 5, for v_dot8_u32_u4
-    if (HASN) return (4u << ((isn ? 4u : code2) * 4u)) | (10u << 20);
+    if (HASN) return (4u << ((isn ? 4u : code2) * 4u)) | (12u << 20) | (1u << 24);
     return 1u << (code2 * 8u);  // one-hot byte per base, for v_dot4_u32_u8
 }
 template <bool HASN>
 __device__ __forceinline__ u32 enc_b(u32 code2, bool isn)
 {
     // what a diag step adds: 4*(S(a,b)+16)+2 = 86 match (N-N included), 66 N-vs-base, 50 mismatch.
-    // dot4 form: byte(a) = that value.  dot8 form: 50 = 10*5 from the constant nibbles, + 4*9 = 36 on a match,
+    // dot4 form: byte(a) = that value.  dot8 form: 48 = 12*4 from constant nibble 5 and the tag 2 = 1*2 from constant
+    // nibble 6 (so that the direction-free blocks can drop the tag by clearing that nibble), + 4*9 = 36 on a match,
     // + 4*4 = 16 when exactly one side is N.
-    if (HASN) return isn ? (0x4444u | (9u << 16) | (5u << 20)) : ((9u << (code2 * 4u)) | (4u << 16) | (5u << 20));
+    if (HASN) return (isn ? (0x4444u | (9u << 16)) : ((9u << (code2 * 4u)) | (4u << 16))) | (4u << 20) | (2u << 24);
     return 0x32323232u + (0x24u << (code2 * 8u));
 }
 
@@ -219,9 +220,9 @@ __device__ __forceinline__ u64 dir_index(int blk, int lane, int c)
 // MODE bit 1 (END): rows of the pos==end_a anti-diagonal and/or the last row are in the block (side captures).
 enum { M_FAST = 0, M_TOP = 1, M_END = 2, M_BOTH = 3 };
 
-// which kernel variants run their fast blocks without directions (do_block_df / materialise): the tuned, N-free ones
+// which kernel variants run their fast blocks without directions (do_block_df / materialise): the tuned band-512 ones
 template <int CE, int C, bool HASN>
-constexpr bool DIRFREE_OK = !HASN && CE >= 0 && CE < C - 1 && C - 1 <= 16 && C >= 9;  // (a loss with 5 columns per lane: 20-column strips, per-row work dominates)
+constexpr bool DIRFREE_OK = CE >= 0 && CE < C - 1 && C - 1 <= 16 && C >= 9;  // (a loss with 5 columns per lane: 20-column strips, per-row work dominates)
 
 template <int C, int CE, bool HASN, int MODE>
 __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t,
@@ -362,7 +363,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 //         hands to that neighbour (its new column 0): [block][received | handed][lane/4 16][row-time 16], written 16 B
 //         (four row-times) at a time so that a strip later reads its 16 row-times of a block as one 64 B line.
 // Values stay multiples of 4 (what the tagged blocks keep after stripping), so fast and slow blocks mix freely.
-template <int C, int CE>
+template <int C, int CE, bool HASN>
 __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int& Lin, int& Lout, const Tk& t, const int blk, const int lane, const int LE)
 {
     static_assert(CE >= 0 && CE < C - 1, "tuned kernels only");
@@ -390,11 +391,12 @@ __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int&
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
-        const u32 brow = ringB_lane[r] - 0x02020202u;  // the ring holds the tagged table
+        const u32 brow = ringB_lane[r] - (HASN ? (2u << 24) : 0x02020202u);  // the ring holds the tagged table
         const int Lrecv = Lin;
         int L = Lin, x = NEG;
         auto cell = [&](const int c) __attribute__((always_inline)) {
-            const int D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
+            const int D = HASN ? (int)__builtin_amdgcn_udot8(W[r + c], brow, (u32)Lp[c], false)
+                               : (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
             int Uc = (c < C - 1) ? Lp[(c < C - 1) ? c + 1 : c] : x;
             if (c == CE) Uc = (int)((u32)Uc | killK);
             L = imax3(D, Uc, L);
@@ -528,7 +530,7 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
         }
         ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
                               __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
-        if constexpr (DF) do_block_df<C, CE>(Lp, W, Lin, Lout, t, blk, lane, LE);
+        if constexpr (DF) do_block_df<C, CE, HASN>(Lp, W, Lin, Lout, t, blk, lane, LE);
         else do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
         a_lo = a_hi; a_hi = a_nx; b_lo = b_hi; b_hi = b_nx;
         if (HASN) { an_lo = an_lo_nx; an_hi = an_hi_nx; bn_lo = bn_lo_nx; bn_hi = bn_hi_nx; }
@@ -542,7 +544,7 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
 // words of those lanes exactly where the tagged fill would have put them.  The walk in finish_task calls it when it
 // enters direction-free blocks whose strip is not there yet; an alignment path drifts sideways only by its net indel
 // count, so nearly every call serves 1 000 rows of path.
-template <int C, int CE>
+template <int C, int CE, bool HASN>
 __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g_hi_, const int lane)
 {
     static_assert(CE >= 0 && CE < C - 1 && C - 1 <= 16, "tuned kernels only");
@@ -581,9 +583,9 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
     const int tau_g = gg * 64;
     const int64_t iaW = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * R + tau_g;  // W[k] <-> a[iaW + k]
     {
-        const u32 aw = fetch16(t.a2, iaW);
+        const u32 aw = fetch16(t.a2, iaW), awn = HASN ? fetch16n(t.an, iaW) : 0u;
 #pragma unroll
-        for (int k = 0; k < C - 1; ++k) W[k] = 1u << (((aw >> (2 * k)) & 3u) * 8u);
+        for (int k = 0; k < C - 1; ++k) W[k] = enc_a<HASN>((aw >> (2 * k)) & 3u, HASN && ((awn >> k) & 1u));
     }
     const u32 tagK = (R == LE) ? 0x80000001u : 1u;
     // the stored boundary values this lane consumes: lam 0 the chain value entering the strip from the left, lam 3 the
@@ -603,20 +605,23 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
     // has just issued)
     const int64_t ia_new = iaW + (C - 1), ib_new = t.b_base + t.begin_b + tau_g - R;
     u32 an_nx = fetch16(t.a2, ia_new), bw_nx = fetch16(t.b2, ib_new);
+    u32 ann_nx = HASN ? fetch16n(t.an, ia_new) : 0u, bwn_nx = HASN ? fetch16n(t.bn, ib_new) : 0u;
     for (int ch = 0; ch < 64 / HR; ++ch) {
-        const u32 an = an_nx, bw = bw_nx;
+        const u32 an = an_nx, bw = bw_nx, ann = ann_nx, bwn = bwn_nx;
         const int nx = min(ch + 1, 64 / HR - 1) * HR;  // the last chunk re-reads itself
         an_nx = fetch16(t.a2, ia_new + nx);
         bw_nx = fetch16(t.b2, ib_new + nx);
+        if (HASN) { ann_nx = fetch16n(t.an, ia_new + nx); bwn_nx = fetch16n(t.bn, ib_new + nx); }
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
-            W[C - 1 + r] = 1u << (((an >> (2 * r)) & 3u) * 8u);
-            const u32 brow = 0x32323232u + (0x24u << (((bw >> (2 * r)) & 3u) * 8u));
+            W[C - 1 + r] = enc_a<HASN>((an >> (2 * r)) & 3u, HASN && ((ann >> r) & 1u));
+            const u32 brow = enc_b<HASN>((bw >> (2 * r)) & 3u, HASN && ((bwn >> r) & 1u));
             const int s = (int)sv[r];
             int L = (lam == 0) ? s : Lin;
             int x = NEG;
             auto cell = [&](const int c) __attribute__((always_inline)) {
-                const int D = (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
+                const int D = HASN ? (int)__builtin_amdgcn_udot8(W[r + c], brow, (u32)Lp[c], false)
+                                   : (int)__builtin_amdgcn_udot4(W[r + c], brow, (u32)Lp[c], false);
                 const int Uc = (c < C - 1) ? (int)((u32)Lp[(c < C - 1) ? c + 1 : c] | ((c == CE) ? tagK : 1u)) : (x | 1);
                 const int Rv = imax3(D, Uc, L);
                 acc[c] = __builtin_amdgcn_alignbit((u32)Rv, acc[c], 2);
@@ -775,7 +780,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                             if (!((l_ >> 2) == mat_q && blk >= mat_lo && blk <= mat_hi)) {
                                 const int g_hi = blk >> 2;
                                 const long long tm0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
-                                materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0)>(tp, l_ >> 2, g_hi, lane);
+                                materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, l_ >> 2, g_hi, lane);
                                 if (dt_flags & TF_DIAG_COUNT_MAT) mat_ticks += wall_clock64() - tm0;
                                 // the loads below must see those stores: wait until L2 has them, then drop this CU's L1
                                 // lines (an agent-scope release would write back the whole L2 of the XCD, far too much)
@@ -803,7 +808,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                     // the middle of the band would ask for, and nothing else
                     if (dt_flags & TF_DIAG_COUNT_MAT)
                         for (int g_hi = (t.df_hi >> 2) - 1; g_hi >= (t.df_lo >> 2); g_hi -= 16)
-                            materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0)>(tp, (Y / 2) / (4 * C), g_hi, lane);
+                            materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, (Y / 2) / (4 * C), g_hi, lane);
                 }
                 x = -1;
             }
