@@ -748,18 +748,8 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
             u32 cw = 0;  // lane 4*k + e holds the direction word of block (cblk0 - k), column 4*cg + e
             // Packed-sequence window for the match counting: lane k holds 2-bit word (w0 - k); the walk moves towards
             // lower indices, so one refill (one coalesced 256 B load) covers the next ~1000 bases.
-            int64_t sa_w0 = INT64_MIN, sb_w0 = INT64_MIN;
-            u32 sa_v = 0, sb_v = 0;
-            auto seq16 = [&](gcptr plane, const int64_t idx, int64_t& w0, u32& v) -> u32 {
-                const int64_t wlo = idx >> 4;
-                if (wlo + 1 > w0 || wlo < w0 - 63) {
-                    w0 = wlo + 1;
-                    v = plane[w0 - lane];
-                }
-                const int k = __builtin_amdgcn_readfirstlane((int)(w0 - wlo));
-                const u32 lo = (u32)__builtin_amdgcn_readlane((int)v, k), hi = (u32)__builtin_amdgcn_readlane((int)v, k - 1);
-                return __builtin_amdgcn_alignbit(hi, lo, (u32)(idx & 15) * 2u);
-            };
+            int64_t sa_w0 = INT64_MIN, sb_w0 = INT64_MIN, san_w0 = INT64_MIN, sbn_w0 = INT64_MIN;
+            u32 sa_v = 0, sb_v = 0, san_v = 0, sbn_v = 0;  // (the N-plane windows only exist in the N-aware kernels)
             // strip of direction-free blocks whose directions materialise() has produced: lanes 4*mat_q .. +3, blocks
             // mat_lo .. mat_hi
             int mat_q = -1, mat_lo = 0, mat_hi = -1, mat_calls = 0;
@@ -822,6 +812,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                 cblk0 = uni(cblk0); cl = uni(cl); cg = uni(cg);
                 mat_q = uni(mat_q); mat_lo = uni(mat_lo); mat_hi = uni(mat_hi); cvalid_lo = uni(cvalid_lo);
                 sa_w0 = uni64(sa_w0); sb_w0 = uni64(sb_w0);
+                if (HASN) { san_w0 = uni64(san_w0); sbn_w0 = uni64(sbn_w0); }
                 if (x == 0 || pos == 0 || want_ops) {
                     // single step with the reference's exact rules
                     const int pa = HASN ? code_at(t.a2, t.an, t.a_base + pos) : (int)((t.a2[(t.a_base + pos) >> 4] >> (((t.a_base + pos) & 15) * 2)) & 3);
@@ -869,7 +860,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         if (++c == C) { c = 0; l++; }
                     }
                     len++;
-                } else if constexpr (!HASN) {
+                } else {
                     // interior: consume a whole run of diagonal steps in one go, with all 64 lanes: the lanes that hold
                     // this column's words of the cached blocks find where the run ends (ballot), then 16 bases per
                     // lane are compared straight out of the two packed-sequence windows.  A single wavefront issues
@@ -908,7 +899,28 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         const u32 b16 = (u32)__builtin_amdgcn_ds_bpermute(4 * (lane + db - da), (int)b16s);
                         const int j = lane - da;
                         const u32 xr = a16 ^ b16;
-                        const u32 ne = (xr | (xr >> 1)) & 0x55555555u;  // bit 2p set: bases p differ
+                        u32 ne = (xr | (xr >> 1)) & 0x55555555u;  // bit 2p set: bases p differ
+                        if constexpr (HASN) {
+                            // a base that is N on either side counts as a MATCH: the 16 mask bits of this lane's chunk
+                            // come out of two 64-word windows of the N planes (32 bases per word), fetched per lane
+                            const int64_t na_lo = ia_hi - 15 - 16 * (int64_t)j, nb_lo = ib_hi - 15 - 16 * (int64_t)j;
+                            const int64_t wna = (ia_hi >> 5) + 1, wnb = (ib_hi >> 5) + 1;  // highest word needed
+                            const int64_t wna_bot = (ia_hi - n - 31) >> 5, wnb_bot = (ib_hi - n - 31) >> 5;
+                            if (wna > san_w0 || wna_bot < san_w0 - 63) { san_w0 = wna; san_v = t.an[san_w0 - lane]; }
+                            if (wnb > sbn_w0 || wnb_bot < sbn_w0 - 63) { sbn_w0 = wnb; sbn_v = t.bn[sbn_w0 - lane]; }
+                            auto nbits = [&](const u32 win, const int64_t w0, const int64_t lo) -> u32 {
+                                const int src = (int)(w0 - (lo >> 5));  // lane holding the word with base `lo`
+                                const u32 wl = (u32)__builtin_amdgcn_ds_bpermute(4 * src, (int)win);
+                                const u32 wh = (u32)__builtin_amdgcn_ds_bpermute(4 * (src - 1), (int)win);
+                                return __builtin_amdgcn_alignbit(wh, wl, (u32)(lo & 31)) & 0xFFFFu;
+                            };
+                            u32 nn = nbits(san_v, san_w0, na_lo) | nbits(sbn_v, sbn_w0, nb_lo);
+                            nn = (nn | (nn << 8)) & 0x00FF00FFu;  // spread the 16 bits to the even positions
+                            nn = (nn | (nn << 4)) & 0x0F0F0F0Fu;
+                            nn = (nn | (nn << 2)) & 0x33333333u;
+                            nn = (nn | (nn << 1)) & 0x55555555u;
+                            ne &= ~nn;
+                        }
                         const int p0 = 16 * j + 16 - n;                 // first base of the chunk that still belongs to the run
                         u32 msk = (p0 <= 0) ? 0x55555555u : ((p0 >= 16) ? 0u : (0x55555555u << (2 * p0)));
                         if (j < 0) msk = 0u;
@@ -946,46 +958,6 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         }
                     } else {
                         const u32 tag = (w_here >> (r * 2)) & 3u;
-                        if (tag == 1u) {  // GAP_A
-                            x--; y++;
-                            if (++c == C) { c = 0; l++; }
-                        } else {  // GAP_B
-                            y--; pos--;
-                            if (--c < 0) { c = C - 1; l--; }
-                        }
-                        len++;
-                    }
-                } else {
-                    // interior: consume a whole run of diagonal steps from one direction word
-                    const int tau = x + l, blk = tau >> 4, r = tau & 15;
-                    const u32 cw = get_word(blk, l, c);
-                    const u32 T = (cw ^ 0xAAAAAAAAu) << (30 - 2 * r);  // pair r on top; diag pairs are 00
-                    int n = T ? (__builtin_clz(T) >> 1) : (r + 1);
-                    n = min(n, min(x, pos));  // stay in x >= 1, pos >= 1
-                    if (n > 0) {
-                        const int64_t ia = t.a_base + pos - n + 1, ib = t.b_base + t.begin_b + x - n + 1;
-                        const u32 xr = seq16(t.a2, ia, sa_w0, sa_v) ^ seq16(t.b2, ib, sb_w0, sb_v);
-                        u32 ne = (xr | (xr >> 1)) & 0x55555555u;  // bit 2k set: bases k differ
-                        if (HASN) {
-                            u32 nn = fetch16n(t.an, ia) | fetch16n(t.bn, ib);  // either is N -> MATCH
-                            // spread 16 bits to even positions
-                            nn = (nn | (nn << 8)) & 0x00FF00FFu;
-                            nn = (nn | (nn << 4)) & 0x0F0F0F0Fu;
-                            nn = (nn | (nn << 2)) & 0x33333333u;
-                            nn = (nn | (nn << 1)) & 0x55555555u;
-                            ne &= ~nn;
-                        }
-                        const u32 msk = (n == 16) ? 0x55555555u : (((1u << (2 * n)) - 1u) & 0x55555555u);
-                        const u32 eq = ~ne & msk;
-                        if (eq) {
-                            nm += (u32)__builtin_popcount(eq);
-                            const int hi = (31 - __builtin_clz(eq)) >> 1, lo = __builtin_ctz(eq) >> 1;
-                            if (!have_last) { have_last = true; la = pos - n + 1 + hi; lb = t.begin_b + x - n + 1 + hi; }
-                            have_first = true; fa = pos - n + 1 + lo; fb = t.begin_b + x - n + 1 + lo;
-                        }
-                        x -= n; pos -= n; len += (u32)n;
-                    } else {
-                        const u32 tag = (cw >> (r * 2)) & 3u;
                         if (tag == 1u) {  // GAP_A
                             x--; y++;
                             if (++c == C) { c = 0; l++; }
