@@ -753,6 +753,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
             // strip of direction-free blocks whose directions materialise() has produced: lanes 4*mat_q .. +3, blocks
             // mat_lo .. mat_hi
             int mat_q = -1, mat_lo = 0, mat_hi = -1, mat_calls = 0;
+            int old_q = -1, old_lo = 0, old_hi = -1;  // the strip materialised before that one
             long long mat_ticks = 0;
             int dg_iters = 0, dg_refills = 0;
             const long long walk_t0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
@@ -767,7 +768,13 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         if (blk >= t.df_hi) {
                             cvalid_lo = t.df_hi;  // the refill may reach down into direction-free blocks: not usable
                         } else if (blk >= t.df_lo) {
-                            if (!((l_ >> 2) == mat_q && blk >= mat_lo && blk <= mat_hi)) {
+                            if ((l_ >> 2) == old_q && blk >= old_lo && blk <= old_hi) {
+                                // back in the strip the walk came from (a path sitting on a strip border): its words
+                                // are still in memory
+                                const int tq = mat_q, tl = mat_lo, th = mat_hi;
+                                mat_q = old_q; mat_lo = old_lo; mat_hi = old_hi;
+                                old_q = tq; old_lo = tl; old_hi = th;
+                            } else if (!((l_ >> 2) == mat_q && blk >= mat_lo && blk <= mat_hi)) {
                                 const int g_hi = blk >> 2;
                                 const long long tm0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
                                 materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, l_ >> 2, g_hi, lane);
@@ -776,6 +783,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                                 // lines (an agent-scope release would write back the whole L2 of the XCD, far too much)
                                 __builtin_amdgcn_s_waitcnt(0);
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                old_q = mat_q; old_lo = mat_lo; old_hi = mat_hi;
                                 mat_q = l_ >> 2; mat_hi = 4 * g_hi + 3; mat_lo = max(4 * (g_hi - 15), t.df_lo);
                                 mat_calls++;
                             }
@@ -811,6 +819,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
 #endif
                 cblk0 = uni(cblk0); cl = uni(cl); cg = uni(cg);
                 mat_q = uni(mat_q); mat_lo = uni(mat_lo); mat_hi = uni(mat_hi); cvalid_lo = uni(cvalid_lo);
+                old_q = uni(old_q); old_lo = uni(old_lo); old_hi = uni(old_hi);
                 sa_w0 = uni64(sa_w0); sb_w0 = uni64(sb_w0);
                 if (HASN) { san_w0 = uni64(san_w0); sbn_w0 = uni64(sbn_w0); }
                 if (x == 0 || pos == 0 || want_ops) {
