@@ -203,6 +203,9 @@ def test_direction_free_fill_and_strip_materialisation():
         a = _cases.rand_seq(rng, n)
         b = _cases.mutate(rng, a, sub, ins, dele)
         cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    a = _cases.rand_seq(rng, 150000, 0.0005)   # long, with a few N runs: the N-aware kernel, 9 000 blocks, 140 groups
+    b = _cases.mutate(rng, a, 0.03, 0.01, 0.01)
+    cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
     a = _cases.rand_seq(rng, 26000)
     b = _cases.mutate(rng, a[3000:], 0.02, 0.01, 0.01)
     cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=3000, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=True, fe=False))
@@ -218,7 +221,7 @@ def test_direction_free_fill_and_strip_materialisation():
             if want_ops:
                 assert r.ops == ops, k
             n_ok += o.status == 0
-    assert n_ok >= 16
+    assert n_ok >= 18
     if not os.environ.get("GAMDP_DIAG_NO_DIRFREE"):
         env = dict(os.environ, GAMDP_DIAG_NO_DIRFREE="1")
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
