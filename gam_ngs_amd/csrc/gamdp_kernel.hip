@@ -166,14 +166,19 @@ __device__ __forceinline__ u32 enc_b(u32 code2, bool isn)
     return 0x32323232u + (0x24u << (code2 * 8u));
 }
 
+// the diag-step tag inside a ring-B entry: the direction-free kernels keep their ring untagged (their hot blocks use it
+// as it is, their few tagged blocks add the tag per row); the other kernels keep it tagged
+template <bool HASN>
+constexpr u32 RING_TAG = HASN ? (2u << 24) : 0x02020202u;
+
 // lanes 0..15 expand the 16 new entries of the block whose first row-time is T
-template <int C, bool HASN>
+template <int C, bool HASN, bool UNTAGGED>
 __device__ __forceinline__ void ring_produce(const int T, const int lane, const u32 aw, const u32 anw, const u32 bw, const u32 bnw)
 {
     if (lane < ROWS) {
         const int kA = T + (C - 1) * 64 + lane;
         RingA<C>::put(kA, enc_a<HASN>((aw >> (2 * lane)) & 3u, HASN && ((anw >> lane) & 1u)));
-        const u32 brow = enc_b<HASN>((bw >> (2 * lane)) & 3u, HASN && ((bnw >> lane) & 1u));
+        const u32 brow = enc_b<HASN>((bw >> (2 * lane)) & 3u, HASN && ((bnw >> lane) & 1u)) - (UNTAGGED ? RING_TAG<HASN> : 0u);
         const int pb = (T + lane) & (RING_B - 1);
         s_ringB[pb] = brow;
         if (pb < ROWS) s_ringB[pb + RING_B] = brow;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void do_block(int (&Lp)[C], u32 (&acc)[C], u32 (&W)[C
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
-        const u32 brow = ringB_lane[r];
+        const u32 brow = ringB_lane[r] + (DIRFREE_OK<CE, C, HASN> ? RING_TAG<HASN> : 0u);
 
         // per-row values of the special modes
         constexpr bool TOP = (MODE & M_TOP) != 0, END = (MODE & M_END) != 0;
@@ -391,7 +396,7 @@ __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int&
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         W[C - 1 + r] = ringA_lane[RingA<C>::transposed ? r * RingA<C>::COLS : r];
-        const u32 brow = ringB_lane[r] - (HASN ? (2u << 24) : 0x02020202u);  // the ring holds the tagged table
+        const u32 brow = ringB_lane[r];  // untagged in these kernels
         const int Lrecv = Lin;
         int L = Lin, x = NEG;
         auto cell = [&](const int c) __attribute__((always_inline)) {
@@ -475,7 +480,7 @@ __device__ __noinline__ void slow_block(BlockState<C>* st, const Tk* tp, const i
         // operands of this block are already in the LDS rings; expand the next block's 16 new bases
         const int T = (blk + 1) * ROWS;
         const int64_t ia = t.a_base + t.begin_a - t.band + T + (C - 1) * 64, ib = t.b_base + t.begin_b + T;
-        ring_produce<C, HASN>(T, lane, fetch16(t.a2, ia), HASN ? fetch16n(t.an, ia) : 0u, fetch16(t.b2, ib),
+        ring_produce<C, HASN, DIRFREE_OK<CE, C, HASN>>(T, lane, fetch16(t.a2, ia), HASN ? fetch16n(t.an, ia) : 0u, fetch16(t.b2, ib),
                               HASN ? fetch16n(t.bn, ib) : 0u);
     }
     do_block<C, CE, HASN, MODE>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
@@ -528,7 +533,7 @@ __device__ __noinline__ void fast_range(BlockState<C>* st, const Tk* tp, const i
             anw = __builtin_amdgcn_alignbit(an_hi, an_lo, (u32)((iA0 + T) & 31)) & 0xFFFFu;
             bnw = __builtin_amdgcn_alignbit(bn_hi, bn_lo, (u32)((iB0 + T) & 31)) & 0xFFFFu;
         }
-        ring_produce<C, HASN>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
+        ring_produce<C, HASN, DIRFREE_OK<CE, C, HASN>>(T, lane, __builtin_amdgcn_alignbit(a_hi, a_lo, sha), anw,
                               __builtin_amdgcn_alignbit(b_hi, b_lo, shb), bnw);
         if constexpr (DF) do_block_df<C, CE, HASN>(Lp, W, Lin, Lout, t, blk, lane, LE);
         else do_block<C, CE, HASN, M_FAST>(Lp, acc, W, Lin, Lout, t, blk, lane, LE, kill_c);
@@ -1002,7 +1007,7 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
 }
 
 // ---- phase A: row 0 -----------------------------------------------------------------------------------
-template <int C, bool HASN>
+template <int C, bool HASN, bool UNTAGGED>
 __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const int lane)
 {
     const Tk t = load_uniform(tp);
@@ -1075,7 +1080,8 @@ __device__ __noinline__ void init_row0(BlockState<C>* st, const Tk* tp, const in
         }
         if (lane < ROWS) {
             const int64_t ib = BB + lane;
-            const u32 brow = enc_b<HASN>((t.b2[ib >> 4] >> ((ib & 15) * 2)) & 3u, HASN && ((t.bn[ib >> 5] >> (ib & 31)) & 1u));
+            const u32 brow = enc_b<HASN>((t.b2[ib >> 4] >> ((ib & 15) * 2)) & 3u, HASN && ((t.bn[ib >> 5] >> (ib & 31)) & 1u)) -
+                             (UNTAGGED ? RING_TAG<HASN> : 0u);
             s_ringB[lane] = brow;
             s_ringB[lane + RING_B] = brow;
         }
@@ -1111,7 +1117,7 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
     const int X = t.X, w = t.band;
     const int LE = (t.Y - 1) / C;  // lane holding the last band column
     BlockState<C> st;
-    init_row0<C, HASN>(&st, &t, lane);
+    init_row0<C, HASN, DIRFREE_OK<CE, C, HASN>>(&st, &t, lane);
 
     // ---- phase B: rows 1..X-1 in blocks of 16 row-times ----------------------------------------------------
     const int nblk = (X - 1 + LE) / ROWS + 1;
