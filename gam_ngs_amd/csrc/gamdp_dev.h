@@ -84,5 +84,6 @@ int kernel_cols(int kid);
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream);
 // occupancy hint: resident waves per CU for this variant
 int kernel_waves_per_cu(int kid);
+int kernel_bnd_words();  // boundary words per block of the direction-free kernels
 
 }  // namespace gamdp

@@ -120,6 +120,7 @@ constexpr int RING_A = 16 * 72;  // 1152 entries: the transposed ring of the 17-
 constexpr int RING_B = 128;
 __shared__ u32 s_ringA[RING_A + ROWS];
 __shared__ u32 s_ringB[RING_B + ROWS];
+__shared__ u32 s_bnd_full[512];  // boundary values of one block on their way out, see do_block_df
 __shared__ int s_cap[2][2][20];  // side-capture scratch [pos==0 | pos==end_a][lane parity], see do_block
 
 // ring A geometry per column count.  Plain layout: size = power of two >= 64*(C-1) + 32.  Transposed layout (C = 17):
@@ -226,6 +227,15 @@ __device__ __forceinline__ u64 dir_index(int blk, int lane, int c)
 enum { M_FAST = 0, M_TOP = 1, M_END = 2, M_BOTH = 3 };
 
 // which kernel variants run their fast blocks without directions (do_block_df / materialise): the tuned band-512 ones
+// strip geometry of the direction-free kernels: SL lanes wide, boundary values stored for every SL-th lane,
+// 64/SL groups re-enacted per materialise() call
+#ifndef GAMDP_STRIP_LANES
+#define GAMDP_STRIP_LANES 4
+#endif
+constexpr int SL = GAMDP_STRIP_LANES, SLOG = (SL == 4) ? 2 : 1, NB = 64 / SL;  // lanes per strip, log2, boundaries per row-time
+static_assert(SL == 2 || SL == 4, "strips are 2 or 4 lanes wide");
+constexpr u32 BND_WORDS = 2u * NB * 16u;  // boundary words per block: [received | handed][lane/SL][row-time 16]
+
 template <int CE, int C, bool HASN>
 constexpr bool DIRFREE_OK = CE >= 0 && CE < C - 1 && C - 1 <= 16 && C >= 9;  // (a loss with 5 columns per lane: 20-column strips, per-row work dominates)
 
@@ -388,9 +398,11 @@ __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int&
 #pragma unroll
         for (int e = 0; e < REM; ++e) ck[G * 256 + lane * REM + e] = (u32)Lp[4 * G + e];
     }
-    gptr bp = t.bnd + (u64)blk * 512u + (u32)(lane >> 2) * 16u;  // [plane 2][lane/4 16][row-time 16]
-    const bool edge = (lane & 3) == 0;
-    u32 keepL[4], keepP[4];  // four row-times of boundary values per 16 B store
+    // boundary values go through LDS ([received | handed][lane/SL][row-time 16]) and leave as one coalesced 2 KB
+    // store per block: scattered 16 B stores from the edge lanes cost the fill 8 %
+    static_assert(BND_WORDS == 512, "s_bnd and the block-end store assume 4-lane strips");
+    u32* const sb = s_bnd_full + (u32)(lane >> SLOG) * 16u;
+    const bool edge = (lane & (SL - 1)) == 0;
     const u32 killK = (lane == LE) ? 0x80000000u : 0u;  // the last band column has no `up` source
     int xkeep = NEG;
 #pragma unroll
@@ -410,17 +422,17 @@ __device__ __forceinline__ void do_block_df(int (&Lp)[C], u32 (&W)[C + 15], int&
         cell(0);
         x = wave_shl1(xkeep, Lp[0]);
         xkeep = x;
-        keepL[r & 3] = (u32)Lrecv;
-        keepP[r & 3] = (u32)Lp[0];
-        if ((r & 3) == 3 && edge) {
-            const u32x4 vl = {keepL[0], keepL[1], keepL[2], keepL[3]}, vp = {keepP[0], keepP[1], keepP[2], keepP[3]};
-            *(g4ptr)(bp + (r - 3)) = vl;
-            *(g4ptr)(bp + 256 + (r - 3)) = vp;
-        }
+        if (edge) { sb[r] = (u32)Lrecv; sb[NB * 16 + r] = (u32)Lp[0]; }
 #pragma unroll
         for (int c = 1; c < C; ++c) cell(c);
         Lout = L;
         Lin = wave_shr1(Lin, L);
+    }
+    {
+        const u32x4 v0 = *(const u32x4*)(s_bnd_full + lane * 8), v1 = *(const u32x4*)(s_bnd_full + lane * 8 + 4);
+        gptr bp = t.bnd + (u64)blk * BND_WORDS + (u32)lane * 8u;
+        *(g4ptr)bp = v0;
+        *(g4ptr)(bp + 4) = v1;
     }
 #pragma unroll
     for (int k = 0; k < C - 1; ++k) W[k] = W[k + ROWS];
@@ -556,10 +568,10 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
     constexpr int HR = 8;  // row-times per unrolled chunk
     const Tk t = load_uniform(tp);
     const int q = uni(q_), g_hi = uni(g_hi_);
-    const int lam = lane & 3;
-    const int R = 4 * q + lam;  // the lane of the fill this lane re-enacts
+    const int lam = lane & (SL - 1);
+    const int R = SL * q + lam;  // the lane of the fill this lane re-enacts
     const int g_first = t.df_lo >> 2;
-    const int g = g_hi - (lane >> 2);
+    const int g = g_hi - (lane >> SLOG);
     const bool live = g >= g_first;
     const int gg = live ? g : g_first;  // lanes beyond the range redo the first group and store nothing
     const int LE = (t.Y - 1) / C;
@@ -582,8 +594,8 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
         for (int c = 0; c < C; ++c) acc[c] = 0;
     }
     // quad shifts: lane lam <- lam-1 / lam+1 of the same strip (the strip's outer lanes take the stored values)
-    auto from_left = [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0x90, 0xf, 0xf, false); };   // quad_perm:[0,0,1,2]
-    auto from_right = [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0xF9, 0xf, 0xf, false); };  // quad_perm:[1,2,3,3]
+    auto from_left = [](int v) { return __builtin_amdgcn_update_dpp(v, v, SL == 4 ? 0x90 : 0xA0, 0xf, 0xf, false); };   // quad_perm:[0,0,1,2] | [0,0,2,2]
+    auto from_right = [](int v) { return __builtin_amdgcn_update_dpp(v, v, SL == 4 ? 0xF9 : 0xF5, 0xf, 0xf, false); };  // quad_perm:[1,2,3,3] | [1,1,3,3]
     int Lin = from_left(Lp[C - 1]);  // what the left neighbour handed over at the end of the previous row-time
     const int tau_g = gg * 64;
     const int64_t iaW = t.a_base + t.begin_a - t.band + (int64_t)(C - 1) * R + tau_g;  // W[k] <-> a[iaW + k]
@@ -595,12 +607,12 @@ __device__ __noinline__ void materialise(const Tk* tp, const int q_, const int g
     const u32 tagK = (R == LE) ? 0x80000001u : 1u;
     // the stored boundary values this lane consumes: lam 0 the chain value entering the strip from the left, lam 3 the
     // `up` hand-off entering from the right (none right of lane 63); lam 1, 2 load the left one and ignore it
-    const bool right_edge = lam == 3;
-    const bool has_right = q < 15;
-    gptr sp = t.bnd + (u64)gg * 2048u + (u32)((right_edge && has_right) ? 256 + (q + 1) * 16 : q * 16);
+    const bool right_edge = lam == SL - 1;
+    const bool has_right = q < NB - 1;
+    gptr sp = t.bnd + (u64)gg * (4u * BND_WORDS) + (u32)((right_edge && has_right) ? NB * 16 + (q + 1) * 16 : q * 16);
     static_assert(HR == 8, "the stream is loaded 4 row-times (16 B) at a time");
     auto load_stream4 = [&](const int chunk, const int half) {  // row-times 4*half .. +3 of a chunk
-        const u32x4 v = *(g4ptr)(sp + (u32)(chunk >> 1) * 512u + (u32)(chunk & 1) * 8u + (u32)half * 4u);
+        const u32x4 v = *(g4ptr)(sp + (u32)(chunk >> 1) * BND_WORDS + (u32)(chunk & 1) * 8u + (u32)half * 4u);
         sv[4 * half] = v.x; sv[4 * half + 1] = v.y; sv[4 * half + 2] = v.z; sv[4 * half + 3] = v.w;
     };
     load_stream4(0, 0);
@@ -773,23 +785,23 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                         if (blk >= t.df_hi) {
                             cvalid_lo = t.df_hi;  // the refill may reach down into direction-free blocks: not usable
                         } else if (blk >= t.df_lo) {
-                            if ((l_ >> 2) == old_q && blk >= old_lo && blk <= old_hi) {
+                            if ((l_ >> SLOG) == old_q && blk >= old_lo && blk <= old_hi) {
                                 // back in the strip the walk came from (a path sitting on a strip border): its words
                                 // are still in memory
                                 const int tq = mat_q, tl = mat_lo, th = mat_hi;
                                 mat_q = old_q; mat_lo = old_lo; mat_hi = old_hi;
                                 old_q = tq; old_lo = tl; old_hi = th;
-                            } else if (!((l_ >> 2) == mat_q && blk >= mat_lo && blk <= mat_hi)) {
+                            } else if (!((l_ >> SLOG) == mat_q && blk >= mat_lo && blk <= mat_hi)) {
                                 const int g_hi = blk >> 2;
                                 const long long tm0 = (dt_flags & TF_DIAG_COUNT_MAT) ? wall_clock64() : 0;
-                                materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, l_ >> 2, g_hi, lane);
+                                materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, l_ >> SLOG, g_hi, lane);
                                 if (dt_flags & TF_DIAG_COUNT_MAT) mat_ticks += wall_clock64() - tm0;
                                 // the loads below must see those stores: wait until L2 has them, then drop this CU's L1
                                 // lines (an agent-scope release would write back the whole L2 of the XCD, far too much)
                                 __builtin_amdgcn_s_waitcnt(0);
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                                 old_q = mat_q; old_lo = mat_lo; old_hi = mat_hi;
-                                mat_q = l_ >> 2; mat_hi = 4 * g_hi + 3; mat_lo = max(4 * (g_hi - 15), t.df_lo);
+                                mat_q = l_ >> SLOG; mat_hi = 4 * g_hi + 3; mat_lo = max(4 * (g_hi - (NB - 1)), t.df_lo);
                                 mat_calls++;
                             }
                             cvalid_lo = (mat_lo == t.df_lo) ? 0 : mat_lo;  // below df_lo the tagged blocks are all there
@@ -810,8 +822,8 @@ __device__ __noinline__ void finish_task(const Tk* tp, const DevTask* dtp_, cons
                     // timing diagnostics: with GAMDP_DIAG_COUNT_MAT as well, do the strip materialisations a walk down
                     // the middle of the band would ask for, and nothing else
                     if (dt_flags & TF_DIAG_COUNT_MAT)
-                        for (int g_hi = (t.df_hi >> 2) - 1; g_hi >= (t.df_lo >> 2); g_hi -= 16)
-                            materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, (Y / 2) / (4 * C), g_hi, lane);
+                        for (int g_hi = (t.df_hi >> 2) - 1; g_hi >= (t.df_lo >> 2); g_hi -= NB)
+                            materialise<C, (DIRFREE_OK<CE, C, HASN> ? CE : 0), HASN>(tp, (Y / 2) / (SL * C), g_hi, lane);
                 }
                 x = -1;
             }
@@ -1195,6 +1207,7 @@ int kernel_cols(int kid)
 }
 
 int kernel_waves_per_cu(int) { return 4 * GAMDP_WAVES_PER_SIMD; }
+int kernel_bnd_words() { return (int)BND_WORDS; }
 
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
 {
