@@ -383,3 +383,29 @@ class PctgBuilder:
             if audit:
                 mb.audit = [MyAlignment.from_result(aud[i * audit + k]) for k in range(min(audit, o.n_dp))]
         return mbs
+
+
+def load_blocks(path: str, min_block_size: int = 1):
+    """Block::loadBlocks (lib/src/assembly/Block.cc:669-690): the blocks of a .blocks file as dicts."""
+    lib = L.load_library()
+    h = C.c_void_p()
+    if lib.gamdp_blocks_open(str(path).encode(), min_block_size, C.byref(h)):
+        raise L.GamdpError("cannot read " + str(path))
+    try:
+        n = lib.gamdp_blocks_count(h)
+        p = lib.gamdp_blocks_data(h)
+        return [p[i].as_dict() for i in range(n)]
+    finally:
+        lib.gamdp_blocks_close(h)
+
+
+def write_blocks(path: str, blocks):
+    """Block::writeBlocks (Block.cc:737-747)."""
+    lib = L.load_library()
+    arr = (L.BlockRec * max(1, len(blocks)))()
+    for r, b in zip(arr, blocks):
+        for k in L.BlockRec.KEYS:
+            v = b[k]
+            setattr(r, k, v.encode("latin1") if isinstance(v, str) else v)
+    if lib.gamdp_blocks_write(str(path).encode(), arr, len(blocks)):
+        raise L.GamdpError("cannot write " + str(path))

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <new>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,19 @@ static int parse_fasta(std::istream& is, Fasta& f)
         f.codes.push_back(std::move(seq));
     }
     return 0;
+}
+
+struct Blocks {
+    std::vector<gamdp_block_rec> recs;
+};
+
+// Frame's operator>> (Frame.cc:207-222): assembly id (ignored), contig id, strand, begin, end, blockReadsLen, readsLen
+// through the stream's own formatted extraction -- what the reference uses, so odd tokens behave alike
+static bool read_frame(std::istream& in, int32_t& ctg, char& strand, int32_t& begin, int32_t& end, uint64_t& block_len, uint64_t& reads_len)
+{
+    int32_t assembly;
+    in >> assembly >> ctg >> strand >> begin >> end >> block_len >> reads_len;
+    return (bool)in;
 }
 
 }  // namespace gamdp
@@ -137,6 +151,57 @@ int gamdp_seqset_create_from_fasta(gamdp_ctx* ctx, const gamdp_fasta* f, gamdp_s
     std::vector<uint64_t> len(x->codes.size());
     for (size_t i = 0; i < x->codes.size(); i++) { ptr[i] = x->codes[i].data(); len[i] = x->codes[i].size(); }
     return gamdp_seqset_create(ctx, ptr.data(), len.data(), (uint32_t)ptr.size(), /*is_ascii=*/0, out);
+}
+
+int gamdp_blocks_open(const char* path, int64_t min_block_size, gamdp_blocks** out)
+{
+    if (!path || !out) return GAMDP_EINVAL;
+    *out = nullptr;
+    std::ifstream ifs(path);
+    if (!ifs) return GAMDP_EINVAL;
+    Blocks* b = new (std::nothrow) Blocks();
+    if (!b) return GAMDP_ENOMEM;
+    std::string line;
+    while (ifs.good()) {
+        std::getline(ifs, line);
+        if (line.empty() || line[0] == '#') continue;
+        std::stringstream ss(line);
+        gamdp_block_rec r;
+        std::memset(&r, 0, sizeof r);
+        long long n = 0;
+        ss >> n;
+        r.n_reads = n;
+        const bool ok = (bool)ss && read_frame(ss, r.m_ctg, r.m_strand, r.m_begin, r.m_end, r.m_block_reads_len, r.m_reads_len) &&
+                        read_frame(ss, r.s_ctg, r.s_strand, r.s_begin, r.s_end, r.s_block_reads_len, r.s_reads_len);
+        if (ok && r.n_reads >= min_block_size) b->recs.push_back(r);
+    }
+    *out = reinterpret_cast<gamdp_blocks*>(b);
+    return 0;
+}
+
+void gamdp_blocks_close(gamdp_blocks* b) { delete reinterpret_cast<Blocks*>(b); }
+uint64_t gamdp_blocks_count(const gamdp_blocks* b) { return b ? reinterpret_cast<const Blocks*>(b)->recs.size() : 0; }
+const gamdp_block_rec* gamdp_blocks_data(const gamdp_blocks* b)
+{
+    const Blocks* x = reinterpret_cast<const Blocks*>(b);
+    return (x && !x->recs.empty()) ? x->recs.data() : nullptr;
+}
+
+int gamdp_blocks_write(const char* path, const gamdp_block_rec* recs, uint64_t n)
+{
+    if (!path || (n && !recs)) return GAMDP_EINVAL;
+    std::ofstream o(path);
+    if (!o) return GAMDP_EINVAL;
+    o << "# MasterAssemblyID\tMasterContigID\tMasterStrand\tMasterBegin\tMasterEnd\tMasterBlockReadsLength\tMasterReadsLength\t"
+      << "SlaveAssemblyID\tSlaveContigID\tSlaveStrand\tSlaveBegin\tSlaveEnd\tSlaveBlockReadsLength\tSlaveReadsLength\n";
+    for (uint64_t i = 0; i < n; i++) {
+        const gamdp_block_rec& r = recs[i];
+        o << (long long)r.n_reads << "\t" << 0 << "\t" << r.m_ctg << "\t" << r.m_strand << "\t" << r.m_begin << "\t" << r.m_end << "\t"
+          << (unsigned long long)r.m_block_reads_len << "\t" << (unsigned long long)r.m_reads_len << "\t" << 0 << "\t" << r.s_ctg << "\t"
+          << r.s_strand << "\t" << r.s_begin << "\t" << r.s_end << "\t" << (unsigned long long)r.s_block_reads_len << "\t"
+          << (unsigned long long)r.s_reads_len << std::endl;
+    }
+    return o.good() ? 0 : GAMDP_EINVAL;
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@ SYMBOLS = [
     "gamdp_pctgs_last_error", "gamdp_pctgs_add_graph", "gamdp_pctgs_finish", "gamdp_pctgs_count",
     "gamdp_pctgs_merged_count", "gamdp_pctgs_codes", "gamdp_pctgs_rows", "gamdp_pctgs_contig_use",
     "gamdp_pctgs_write_fasta", "gamdp_pctgs_write_descriptors",
+    "gamdp_blocks_open", "gamdp_blocks_close", "gamdp_blocks_count", "gamdp_blocks_data", "gamdp_blocks_write",
 ]
 
 EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
@@ -77,6 +78,21 @@ class MBlock(C.Structure):
 class PctgRow(C.Structure):
     _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("ctg_id", C.c_int32), ("reversed", C.c_uint8),
                 ("is_master", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+
+
+class BlockRec(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("m_block_reads_len", C.c_uint64), ("m_reads_len", C.c_uint64),
+                ("s_block_reads_len", C.c_uint64), ("s_reads_len", C.c_uint64), ("m_ctg", C.c_int32),
+                ("m_begin", C.c_int32), ("m_end", C.c_int32), ("s_ctg", C.c_int32), ("s_begin", C.c_int32),
+                ("s_end", C.c_int32), ("m_strand", C.c_char), ("s_strand", C.c_char), ("pad_", C.c_uint8 * 6)]
+
+    KEYS = ("n_reads", "m_ctg", "m_strand", "m_begin", "m_end", "m_block_reads_len", "m_reads_len",
+            "s_ctg", "s_strand", "s_begin", "s_end", "s_block_reads_len", "s_reads_len")
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k in self.KEYS}
+        d["m_strand"], d["s_strand"] = d["m_strand"].decode("latin1"), d["s_strand"].decode("latin1")
+        return d
 
 
 REGION_VOTE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
@@ -164,5 +180,13 @@ def load_library():
     lib.gamdp_pctgs_contig_use.argtypes = [vp, vp, vp]
     lib.gamdp_pctgs_write_fasta.argtypes = [vp, C.c_char_p]
     lib.gamdp_pctgs_write_descriptors.argtypes = [vp, C.c_char_p]
+    lib.gamdp_blocks_open.argtypes = [C.c_char_p, C.c_int64, C.POINTER(vp)]
+    lib.gamdp_blocks_close.argtypes = [vp]
+    lib.gamdp_blocks_close.restype = None
+    lib.gamdp_blocks_count.argtypes = [vp]
+    lib.gamdp_blocks_count.restype = u64
+    lib.gamdp_blocks_data.argtypes = [vp]
+    lib.gamdp_blocks_data.restype = C.POINTER(BlockRec)
+    lib.gamdp_blocks_write.argtypes = [C.c_char_p, C.POINTER(BlockRec), u64]
     _lib = lib
     return lib

@@ -157,6 +157,26 @@ const uint8_t* gamdp_fasta_codes(const gamdp_fasta* f, uint32_t i, uint64_t* len
 /* sequence i of the set = record i of the file */
 int gamdp_seqset_create_from_fasta(gamdp_ctx* ctx, const gamdp_fasta* f, gamdp_seqset** out);
 
+/* ---- .blocks files (gam-create's output, gam-merge's input; lib/src/assembly/Block.cc:669-690, 737-747, 795-807,
+ *      Frame.cc:197-222) -------------------------------------------------------------------------------------- */
+/* One line = numReads, then for the master and for the slave frame: 0 ctgId strand begin end blockReadsLen readsLen
+ * (tab separated on output, any blanks on input).  Lines that are empty or start with '#' are skipped, lines that do
+ * not parse are dropped silently, blocks with numReads < min_block_size are dropped (loadBlocks, :669-690). */
+typedef struct gamdp_block_rec {
+    int64_t n_reads;
+    uint64_t m_block_reads_len, m_reads_len, s_block_reads_len, s_reads_len;
+    int32_t m_ctg, m_begin, m_end, s_ctg, s_begin, s_end;
+    char m_strand, s_strand;
+    uint8_t pad_[6];
+} gamdp_block_rec;
+typedef struct gamdp_blocks gamdp_blocks;
+int gamdp_blocks_open(const char* path, int64_t min_block_size, gamdp_blocks** out);
+void gamdp_blocks_close(gamdp_blocks* b);
+uint64_t gamdp_blocks_count(const gamdp_blocks* b);
+const gamdp_block_rec* gamdp_blocks_data(const gamdp_blocks* b);
+/* writeBlocks (:737-747): the header line, then one block per line */
+int gamdp_blocks_write(const char* path, const gamdp_block_rec* recs, uint64_t n);
+
 /* ---- L0: batch of independent banded alignments ------------------------------------------- */
 /* a sequences come from set_a, b sequences from set_b (may be the same set). */
 int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seqset* set_b,

@@ -7,4 +7,4 @@ make -C gam_ngs_amd/csrc asan -j8 > /dev/null
 RT=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so' | head -1)
 ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$RT \
 GAMDP_LIB=$PWD/gam_ngs_amd/csrc/build/libgamdp_asan.so \
-python -m pytest tests/test_pctg_stage.py tests/test_cabi_symbols.py tests/test_oracle_golden.py -x -q
+python -m pytest tests/test_pctg_stage.py tests/test_blocks_io.py tests/test_cabi_symbols.py tests/test_oracle_golden.py -x -q
