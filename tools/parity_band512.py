@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Focused parity run for the direction-free band-512 kernels: random windowed cases of 0.6-14 kb (so that the
+direction-free range is empty, one group, a few groups ...), with and without N, with and without edit strings, and
+once more with a tiny scratch arena (few resident slots, several launches)."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _cases  # noqa: E402
+import _oracle as O  # noqa: E402
+import _gpu  # noqa: E402
+from _gpu import oracle_for, run_cases  # noqa: E402
+
+
+def main():
+    n_total = 0
+    for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+        rng = random.Random(5120 + seed)
+        cases = []
+        for _ in range(60):
+            n = rng.choice([600, 900, 1300, 2000, 3000, 5000, 8000, 14000])
+            a = _cases.rand_seq(rng, n, 0.002 if rng.random() < 0.3 else 0.0)
+            b = _cases.mutate(rng, a[rng.randint(0, 200):], 0.03, rng.choice([0.0, 0.01, 0.03]), rng.choice([0.0, 0.01, 0.03]))
+            if not b:
+                b = "A"
+            ba = rng.choice([0, 0, rng.randint(0, 700), rng.randint(0, n - 1)])
+            ea = rng.choice([n - 1, n - 1, rng.randint(ba, n + 600)])
+            bb = rng.choice([0, 0, rng.randint(0, min(300, len(b) - 1))])
+            eb = rng.choice([len(b) - 1, len(b) - 1, rng.randint(bb, len(b) + 50)])
+            cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb,
+                              fs=rng.random() < 0.2, fe=rng.random() < 0.2))
+        if seed % 3 == 2:
+            _gpu.ctx().set_arena_bytes(40 << 20)   # a handful of slots
+        for want_ops in (False, True):
+            res = run_cases(cases, want_ops=want_ops)
+            for cs, r in zip(cases, res):
+                o, ops = oracle_for(cs, want_ops)
+                if o.status == O.INVALID:
+                    continue
+                n_total += 1
+                if r.key() != o.key() or (want_ops and r.ops != ops):
+                    print("MISMATCH seed", seed, {k: v for k, v in cs.items() if k not in ("a", "b")}, len(cs["a"]), len(cs["b"]), r.key(), o.key())
+                    sys.exit(1)
+    print("band-512 parity passed:", n_total, "comparisons")
+
+
+if __name__ == "__main__":
+    main()
