@@ -93,8 +93,10 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
             while (b0 < nblk && mode_of(b0) != M_FAST) ++b0;
             int b1 = b0;
             while (b1 < nblk && mode_of(b1) == M_FAST) ++b1;
-            const int lo = (b0 + 1 + 3) & ~3, hi = b1 & ~3;
-            if (hi - lo >= 8) { t.df_lo = lo; t.df_hi = hi; }
+            int b2 = b1;  // the end blocks that follow run direction-free too, as far as whole groups go
+            while (b2 < nblk && mode_of(b2) == M_END) ++b2;
+            const int lo = (b0 + 1 + 3) & ~3, hi = b2 & ~3;
+            if (hi - lo >= 8 && b1 > lo) { t.df_lo = lo; t.df_hi = hi; }
         }
     }
     for (int blk = 0; blk < nblk;) {
@@ -105,9 +107,14 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
             if constexpr (DIRFREE_OK<CE, C, HASN>) {
                 if (blk < t.df_hi && e > t.df_lo && t.df_hi > t.df_lo) {  // this is the run that holds the direction-free groups
                     if (blk < t.df_lo) fast_range<C, CE, HASN, false>(&st, &t, blk, t.df_lo, lane);
-                    fast_range<C, CE, HASN, true>(&st, &t, t.df_lo, t.df_hi, lane);
-                    if (t.df_hi < e) fast_range<C, CE, HASN, false>(&st, &t, t.df_hi, e, lane);
+                    const int f_hi = min(t.df_hi, e);  // e = first block after the fast run
+                    fast_range<C, CE, HASN, true>(&st, &t, t.df_lo, f_hi, lane);
+                    if (f_hi < e) fast_range<C, CE, HASN, false>(&st, &t, f_hi, e, lane);
                     blk = e;
+                    if (t.df_hi > e) {  // end blocks of the direction-free range
+                        fast_range<C, CE, HASN, true, true>(&st, &t, e, t.df_hi, lane);
+                        blk = t.df_hi;
+                    }
                     continue;
                 }
             }
