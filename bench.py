@@ -2,24 +2,35 @@
 """Benchmark of the hot path on BASELINE.json's workload: GCUPS of the banded semi-global DP on
 synthetic 50 kb x 50 kb contig pairs (5 % divergence, band 512; generator of SURVEY.md 8d).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--scaling strong|weak]
 
-One "step" = one gamdp_align_batch call over this rank's P pairs (fill + end-cell search + traceback
-summary for every pair), sequences already packed and resident in HBM.  For N > 1 the driver starts
-one process per GPU with torch.distributed.run; every rank aligns its own P pairs (the pair list is
-statically partitioned, no data-path collective) -> weak scaling; value = total cells / max-over-ranks time.
+One "step" = one gamdp_align_batch call over this rank's pairs (fill + end-cell search + traceback summary for
+every pair), sequences already packed and resident in HBM.  N > 1 = one process per GPU (the driver starts them
+with torch.distributed.run; `python bench.py --gpus N` on its own spawns the same thing as a child process).
+
+  --scaling strong (default)  BASELINE config 5 as written: ONE fixed list of P pairs (100 000), dealt over the N
+                              GPUs by the library's partitioner (gamdp_partition_lpt on predicted cells: equal
+                              weights -> round-robin); value = P pairs' cells / max-over-ranks time.
+  --scaling weak              every rank aligns its own P pairs; value = N*P pairs' cells / max-over-ranks time.
+With N > 1 the strong-scaling line also carries a short weak-scaling measurement ("weak": {...}).
+There is no data-path collective in either mode; RCCL only carries the barrier and three timing scalars.
 
 The printed JSON line also carries
-  roofline      algorithmic HBM bytes (0.2507 B per cell update) of one kernel launch
-                divided by that launch's HIP-event duration, against the 8 TB/s HBM peak;
-  cpu_baseline  the reference's own find_alignment (oracle/_ref, kind "reference") or, where that build
-                is absent, our C restatement (oracle/, kind "port"), timed on this box's host cores on a
-                bounded sample of the same pairs.
+  roofline        algorithmic HBM bytes (0.2507 B per cell update) of one kernel launch divided by
+                  that launch's HIP-event duration (the library's own stream), against the 8 TB/s HBM peak;
+  cpu_baseline    the reference's own find_alignment (oracle/_ref, kind "reference") or, where that build is
+                  absent, our C restatement (oracle/, kind "port"), timed on this box's host cores on a bounded
+                  sample of the same pairs (rank 0, N = 1 only);
+  verified_pairs  how many of those CPU results were compared field for field with the GPU results of the same
+                  pairs (outside the timed region); any difference fails the run;
+  l1              the merge-block driver (gamdp_align_merge_blocks, band 150) on a GAGE-shaped synthetic
+                  two-assembly workload: merge blocks/s, GCUPS, share of the call spent in GPU kernels, rounds.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,43 +41,78 @@ B_ALG = 0.2507          # algorithmic HBM bytes per cell update (SURVEY.md 8d / 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(length, band, first_pair, budget_pairs):
-    """Times the CPU path on `budget_pairs` pairs with all host cores. Test infrastructure (oracle/) is
-    used here only as the thing being timed for the reported baseline -- never by the product path."""
+def reduce_step_stats(dt, cells, failed, device=None):
+    """(max over ranks of dt, sum of cells, sum of failed) -- identity when not distributed."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dt, cells, failed
+    t = torch.tensor([dt, cells, failed], dtype=torch.float64, device=device)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone()
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return tmax[0].item(), tsum[1].item(), tsum[2].item()
+
+
+def rank_share(n_items, rank, world, weights=None):
+    """Indices of the fixed list this rank owns: the library's deterministic LPT partition (every rank computes the
+    same one).  The benchmark's pairs have equal predicted cells, so this is a round-robin deal."""
+    from gam_ngs_amd import api
+    part = api.partition_lpt(weights if weights is not None else [1] * n_items, world)
+    return [i for i, p in enumerate(part) if p == rank]
+
+
+def cpu_baseline(length, band, pair_ids):
+    """Times the CPU path on the given pairs with all host cores and returns (record, results).  Test infrastructure
+    (oracle/) is used here only as the thing being timed for the reported baseline and as the checker of the GPU
+    results -- never by the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     from gam_ngs_amd import api
+    n = len(pair_ids)
     # the reference allocates a 410 MB matrix per in-flight 50 kb pair: cap the pool so the host stays safe
     threads = min(os.cpu_count() or 1, 16)
     ref = O.ref()
+    keys = []
     if ref is not None and hasattr(ref, "gamref_bench_pairs"):
-        pairs = [api.synth_pair(first_pair + k, length) for k in range(budget_pairs)]
+        pairs = [api.synth_pair(k, length) for k in pair_ids]
         a = [api.decode(m).encode() for m, _ in pairs]
         b = [api.decode(s).encode() for _, s in pairs]
-        arr_a = (C.c_char_p * budget_pairs)(*a)
-        arr_b = (C.c_char_p * budget_pairs)(*b)
-        la = (C.c_uint64 * budget_pairs)(*[len(x) for x in a])
-        lb = (C.c_uint64 * budget_pairs)(*[len(x) for x in b])
+        arr_a, arr_b = (C.c_char_p * n)(*a), (C.c_char_p * n)(*b)
+        la, lb = (C.c_uint64 * n)(*[len(x) for x in a]), (C.c_uint64 * n)(*[len(x) for x in b])
+        res = (O.RefResult * n)()
         ref.gamref_bench_pairs.restype = C.c_uint64
         ref.gamref_bench_pairs.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p),
-                                           C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+                                           C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int, C.POINTER(O.RefResult)]
         t0 = time.time()
-        cells = ref.gamref_bench_pairs(arr_a, la, arr_b, lb, budget_pairs, band, threads, None)
+        cells = ref.gamref_bench_pairs(arr_a, la, arr_b, lb, n, band, threads, res)
         dt = time.time() - t0
         kind = "reference"
+        keys = [O.ref_key(res[i]) for i in range(n)]
     else:
+        contiguous = all(pair_ids[i] == pair_ids[0] + i for i in range(n))
+        if not contiguous:
+            raise SystemExit("the oracle's bench entry takes a contiguous pair range")
+        res = (O.OracleResult * n)()
+        fn = O.oracle().gamdp_oracle_bench_pairs
+        fn.restype = C.c_uint64
+        fn.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(O.OracleResult)]
         t0 = time.time()
-        cells = O.oracle().gamdp_oracle_bench_pairs(first_pair, budget_pairs, length, band, threads, None)
+        cells = fn(pair_ids[0], n, length, band, threads, res)
         dt = time.time() - t0
         kind = "port"
-    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": threads, "kind": kind,
-            "sample": "%d of the same synthetic %d bp pairs (band %d), %d threads, %.1f s" %
-                      (budget_pairs, length, band, threads, dt)}
+        keys = [res[i].key() for i in range(n)]
+    rec = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": threads, "kind": kind,
+           "sample": "%d of the same synthetic %d bp pairs (band %d), %d threads, %.1f s" % (n, length, band, threads, dt)}
+    return rec, keys
 
 
 def kernel_name(band):
     """The k_align instantiation the library picks for N-free contigs of this band (gamdp_host.cpp pick_kernel)."""
-    n = "true" if os.environ.get("GAMDP_DIAG_FORCE_N") else "false"
+    from gam_ngs_amd import lib as L
+    forced_n = bool(os.environ.get("GAMDP_DIAG_FORCE_N")) and L.load_library().gamdp_build_info() & 1
+    n = "true" if forced_n else "false"
     if band == 512:
         return "k_align<17,4,%s>" % n
     if band == 150:
@@ -76,18 +122,59 @@ def kernel_name(band):
     return "k_align<%d,-1,true>" % c
 
 
+def measured_traffic(P_launch, length, band, launches_ok):
+    """HBM bytes per launch from the PMC counters.  FETCH_SIZE / WRITE_SIZE need their own rocprofv3 passes, so the
+    figure is REPLAYED from the newest committed profile of exactly this workload (its file and the commit it was
+    collected on are named in the line); null when the workload differs or no profile exists."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(pdir, name)))
+                w = tj["workload"]
+                if (w["pairs_per_launch"], w["len"], w["band"]) == (P_launch, length, band) and launches_ok:
+                    best = (name, tj)
+            except (OSError, KeyError, ValueError):
+                pass
+    if best is None:
+        return None, None, None
+    name, tj = best
+    return tj["hbm_bytes_per_launch"], "profiles/" + name, tj.get("commit")
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (this parent has
+    not touched the GPU and never will) and leave with its exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=100000,
-                    help="pairs per GPU per step (default: all 100 k pairs of BASELINE config 5)")
+                    help="strong: pairs in the fixed list (default: all 100 k pairs of BASELINE config 5); weak: per GPU")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--len", type=int, default=50000)
     ap.add_argument("--band", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = 2 per core)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = 32 per core)")
+    ap.add_argument("--no-l1", action="store_true", help="skip the merge-block (L1, band 150) record")
+    ap.add_argument("--l1-genome", type=int, default=2_900_000, help="genome size of the L1 workload (S. aureus: 2.9 Mb)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -108,27 +195,12 @@ def main():
     torch.cuda.set_device(local_rank)
 
     import gam_ngs_amd as gam
-    from gam_ngs_amd import api, lib as L
+    from gam_ngs_amd import lib as L
 
+    if L.load_library().gamdp_build_info() & 1:
+        print("bench.py: WARNING: running on the diagnostics build (GAMDP_LIB); not a product measurement", file=sys.stderr)
     ctx = gam.Context(local_rank)
-    P, length, band = args.pairs, args.len, args.band
-    first = rank * P  # static partition of the pair list: rank r owns pairs [r*P, (r+1)*P)
-    # pairs are generated + packed inside the library (same generator as gamdp_synth_pair / the oracle) and
-    # uploaded once: sequence 2k = master, 2k+1 = slave of pair first+k
-    t_setup = time.perf_counter()
-    sset = gam.SequenceSet.synthetic(ctx, first, P, length)
-    t_setup = time.perf_counter() - t_setup
-    tasks = (L.Task * P)()
-    for k in range(P):
-        t = tasks[k]
-        t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, band
-        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, length - 1, 0, sset.lengths[2 * k + 1] - 1
-    out = (L.Result * P)()
-
-    def step():
-        rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
-        if rc != 0:
-            raise SystemExit("gamdp_align_batch failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+    length, band = args.len, args.band
 
     def barrier():
         if world > 1:
@@ -137,60 +209,111 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.kernel_time(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = ctx.kernel_time()
+    def measure(mode, steps, warmup):
+        """One timed run in `mode`; returns the numbers of the JSON line (rank 0 uses them)."""
+        if mode == "strong":
+            ids = rank_share(args.pairs, rank, world)     # equal weights: pair i -> rank i % world
+            first, stride, P = (ids[0] if ids else 0), world, len(ids)
+            assert ids == [first + k * stride for k in range(P)]
+        else:
+            first, stride, P = rank * args.pairs, 1, args.pairs
+        t_setup = time.perf_counter()
+        # pairs are generated + packed inside the library (same generator as gamdp_synth_pair / the oracle) and
+        # uploaded once: sequence 2k = master, 2k+1 = slave of this rank's k-th pair
+        sset = gam.SequenceSet.synthetic(ctx, first, P, length, stride=stride)
+        t_setup = time.perf_counter() - t_setup
+        tasks = (L.Task * max(1, P))()
+        for k in range(P):
+            t = tasks[k]
+            t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, band
+            t.begin_a, t.end_a, t.begin_b, t.end_b = 0, length - 1, 0, sset.lengths[2 * k + 1] - 1
+        out = (L.Result * max(1, P))()
 
-    cells_rank = sum(out[k].cells for k in range(P))
-    bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
-    from gam_ngs_amd import shard
-    dt_max, cells_all, bad_all = shard.reduce_step_stats(dt, float(cells_rank), float(bad),
-                                                         device="cpu" if share_gpu else "cuda")
+        def step():
+            rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
+            if rc != 0:
+                raise SystemExit("gamdp_align_batch failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+
+        for _ in range(warmup):
+            step()
+        ctx.kernel_time(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = ctx.kernel_time()
+        cells_rank = sum(out[k].cells for k in range(P))
+        bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
+        dt_max, cells_all, bad_all = reduce_step_stats(dt, float(cells_rank), float(bad), device="cpu" if share_gpu else "cuda")
+        m = dict(P=P, first=first, stride=stride, dt_max=dt_max, cells_all=cells_all, bad_all=bad_all, cells_rank=cells_rank,
+                 kernel_ms=kernel_ms, launches=launches, t_setup=t_setup, gcups=cells_all * steps / dt_max / 1e9,
+                 keys=None)
+        if rank == 0 and mode == args.scaling:
+            m["gpu_keys"] = lambda n: [out[k].key() for k in range(n)]
+            m["_keep"] = (sset, tasks, out)
+        else:
+            sset.close()
+        return m
+
+    m = measure(args.scaling, args.steps, args.warmup)
+    weak = None
+    if world > 1 and args.scaling == "strong":
+        w = measure("weak", 1, 1)
+        weak = {"value": w["gcups"], "unit": "GCUPS", "pairs_per_gpu_per_step": w["P"], "steps": 1,
+                "ms_per_step": w["dt_max"] * 1e3}
 
     if rank == 0:
-        gcups = cells_all * args.steps / dt_max / 1e9
-        avg_launch_s = (kernel_ms / 1e3) / max(1, launches)
-        cells_per_launch = cells_rank * args.steps / max(1, launches)
+        steps = args.steps
+        launches = m["launches"]
+        avg_launch_s = (m["kernel_ms"] / 1e3) / max(1, launches)
+        cells_per_launch = m["cells_rank"] * steps / max(1, launches)
         achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE need their own rocprofv3 passes, so
-        # they are taken from the committed profile of this same workload; null when the workload differs)
-        traffic = traffic_bytes = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            w = tj["workload"]
-            if (w["pairs_per_launch"], w["len"], w["band"]) == (P, length, band) and launches == args.steps:
-                traffic_bytes = tj["hbm_bytes_per_launch"]
-                traffic = traffic_bytes / avg_launch_s / 1e9
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic_bytes, traffic_src, traffic_commit = measured_traffic(m["P"], length, band, launches == steps)
         line = {
-            "metric": "GCUPS", "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "metric": "GCUPS", "value": m["gcups"], "unit": "GCUPS", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": m["dt_max"] / steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "synthetic %d bp x ~%d bp contig pairs, 5%% divergence, band %d "
                                    "(BASELINE.json config 5 generator), find_alignment incl. traceback summary"
                                    % (length, length, band),
-                       "pairs_per_gpu_per_step": P, "cells_per_pair": cells_rank // P,
-                       "parallelism": "pair list statically partitioned over %d GPU(s), no collective" % world,
-                       "failed_pairs": int(bad_all),
-                       "one_time_setup_s": round(t_setup, 3)},  # generate + pack + upload the sequences (not timed)
+                       "pairs_total_per_step": int(args.pairs if args.scaling == "strong" else args.pairs * world),
+                       "pairs_on_rank0_per_step": m["P"], "cells_per_pair": m["cells_rank"] // max(1, m["P"]),
+                       "parallelism": ("one fixed pair list dealt over %d GPU(s) by gamdp_partition_lpt, no collective" % world)
+                       if args.scaling == "strong" else ("%d GPU(s) x their own pairs, no collective" % world),
+                       "failed_pairs": int(m["bad_all"]),
+                       "one_time_setup_s": round(m["t_setup"], 3)},  # generate + pack + upload the sequences (not timed)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic_bytes / avg_launch_s / 1e9) if traffic_bytes and avg_launch_s > 0 else None,
                          "traffic_bytes_per_launch": traffic_bytes,
+                         "traffic_source": ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                            "workload, collected at commit %s), divided by this run's kernel time"
+                                            % (traffic_src, traffic_commit or "unrecorded")) if traffic_src else None,
                          "algorithmic_bytes_per_launch": cells_per_launch * B_ALG,
                          "kernel": kernel_name(args.band), "kernel_ms_per_launch": avg_launch_s * 1e3,
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
-        if not args.no_cpu_baseline:
-            n_cpu = args.cpu_pairs or 32 * min(os.cpu_count() or 1, 16)
-            line["cpu_baseline"] = cpu_baseline(length, band, first, min(n_cpu, P))
+        if weak is not None:
+            line["weak"] = weak
+        if m["bad_all"]:
+            raise SystemExit("bench.py: %d pairs came back without an alignment" % int(m["bad_all"]))
+        if not args.no_cpu_baseline and world == 1:
+            n_cpu = min(args.cpu_pairs or 32 * min(os.cpu_count() or 1, 16), m["P"])
+            ids = [m["first"] + k * m["stride"] for k in range(n_cpu)]
+            rec, cpu_keys = cpu_baseline(length, band, ids)
+            line["cpu_baseline"] = rec
+            gpu_keys = m["gpu_keys"](n_cpu)
+            diff = [k for k in range(n_cpu) if tuple(gpu_keys[k]) != tuple(cpu_keys[k])]
+            if diff:
+                k = diff[0]
+                raise SystemExit("bench.py: GPU result of pair %d differs from the CPU %s: %r vs %r (%d of %d differ)"
+                                 % (ids[k], rec["kind"], gpu_keys[k], cpu_keys[k], len(diff), n_cpu))
+            line["verified_pairs"] = n_cpu   # status, begin, score, #matches, length, first/last match, identity
+        if not args.no_l1 and world == 1:
+            import bench_l1
+            line["l1"] = bench_l1.run(ctx, genome=args.l1_genome)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""The merge-block (L1) record of bench.py: gamdp_align_merge_blocks at band 150 (gam-merge's only live band,
+banded_smith_waterman.hpp:38) on the GAGE-shaped synthetic two-assembly workload of tests/_gage.py (stand-in for
+BASELINE configs 1-4, whose data cannot be fetched here).  One step = ONE call over all merge blocks of all graphs.
+
+    python bench_l1.py [--genome 2900000] [--steps 5]          # on its own; bench.py embeds run() as "l1": {...}
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def marshal(flat):
+    """merge blocks (dicts of tests/_gage.py) -> (gamdp_mb_in array, keep-alive list)"""
+    from gam_ngs_amd import lib as L
+    n = len(flat)
+    ins = (L.MbIn * max(1, n))()
+    keep = []
+    for i, mb in enumerate(flat):
+        nb = len(mb["blocks"])
+        arr = (L.BlockC * max(1, nb))()
+        for k, b in enumerate(mb["blocks"]):
+            arr[k].m_begin, arr[k].m_end, arr[k].s_begin, arr[k].s_end = b[0], b[1], b[2], b[3]
+            arr[k].m_strand, arr[k].s_strand, arr[k].n_reads = b[4].encode(), b[5].encode(), b[6]
+        keep.append(arr)
+        x = ins[i]
+        x.m_id, x.s_id = mb["m_id"], mb["s_id"]
+        x.m_ltail, x.m_rtail, x.s_ltail, x.s_rtail = [int(t) for t in mb["tails"]]
+        x.n_blocks = nb
+        x.blocks = C.cast(arr, C.POINTER(L.BlockC))
+    return ins, keep
+
+
+def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150):
+    """Returns the "l1" object of the bench line.  `verify` merge blocks are checked against the CPU oracle's driver
+    (oracle/, checker only) outside the timed region; a difference fails the run."""
+    import _gage
+    import gam_ngs_amd as gam
+    from gam_ngs_amd import lib as L
+    t0 = time.perf_counter()
+    pb = _gage.problem(seed, genome_len=genome)
+    flat, _ = _gage.merge_blocks(pb)
+    masters = gam.SequenceSet(ctx, [bytes(c["seq"]) for c in pb["master"]], ascii=False)
+    slaves = gam.SequenceSet(ctx, [bytes(c["seq"]) for c in pb["slave"]], ascii=False)
+    ins, keep = marshal(flat)
+    n = len(flat)
+    outs = (L.MbOut * max(1, n))()
+    t_setup = time.perf_counter() - t0
+
+    def step():
+        rc = ctx.lib.gamdp_align_merge_blocks(ctx.handle, masters.handle, slaves.handle, ins, n, band, outs, None, 0)
+        if rc != 0:
+            raise SystemExit("gamdp_align_merge_blocks failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+
+    for _ in range(warmup):
+        step()
+    acc = dict(wall=0.0, busy=0.0, ksum=0.0, pend=0.0, feed=0.0)
+    st = L.L1Stats()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        ctx.lib.gamdp_ctx_l1_stats(ctx.handle, C.byref(st))
+        acc["wall"] += st.wall_ms; acc["busy"] += st.gpu_busy_ms; acc["ksum"] += st.kernel_sum_ms
+        acc["pend"] += st.host_pending_ms; acc["feed"] += st.host_feed_ms
+    dt = (time.perf_counter() - t1) / steps
+    rec = {
+        "workload": "GAGE-shaped synthetic: %.1f Mb genome, %d + %d contigs, %d merge blocks in %d graphs, band %d"
+                    % (genome / 1e6, len(pb["master"]), len(pb["slave"]), n, len(pb["graphs"]), band),
+        "merge_blocks": n, "dp_calls": int(st.dp_calls), "cells": int(st.cells), "steps": steps,
+        "ms_per_step": dt * 1e3, "merge_blocks_per_s": n / dt, "gcups": st.cells / dt / 1e9,
+        "gpu_busy_frac": acc["busy"] / acc["wall"] if acc["wall"] else 0.0,
+        "gpu_busy_ms": acc["busy"] / steps, "kernel_sum_ms": acc["ksum"] / steps,
+        "host_pending_ms": acc["pend"] / steps, "host_feed_ms": acc["feed"] / steps,
+        "rounds": int(st.rounds), "cohorts": int(st.cohorts), "launches": int(st.launches),
+        "align_ok": sum(1 for i in range(n) if outs[i].align_ok), "setup_s": round(t_setup, 2),
+    }
+    if verify:
+        from _l1oracle import oracle_mb
+        # the cheapest merge blocks keep the CPU check to seconds; every decision field is compared
+        order = sorted(range(n), key=lambda i: sum(b[1] - b[0] for b in flat[i]["blocks"]))[:verify]
+        for i in order:
+            mb = flat[i]
+            sc = dict(master=_gage.to_ascii(pb["master"][mb["m_id"]]["seq"]).decode(),
+                      slave=_gage.to_ascii(pb["slave"][mb["s_id"]]["seq"]).decode(), blocks=mb["blocks"], tails=mb["tails"])
+            o, _ = oracle_mb(sc, band=band, audit_cap=1)
+            got = (outs[i].status, bool(outs[i].align_ok), bool(outs[i].coords_set), outs[i].n_dp, outs[i].cells)
+            want = (o.status, bool(o.align_ok), bool(o.touched), o.n_dp, o.cells)
+            if o.touched:
+                got += (bool(outs[i].align_rev), outs[i].m_start, outs[i].m_end, outs[i].s_start, outs[i].s_end)
+                want += (bool(o.align_rev), o.m_start, o.m_end, o.s_start, o.s_end)
+            if got != want:
+                raise SystemExit("bench_l1: merge block %d differs from the CPU oracle: %r vs %r" % (i, got, want))
+        rec["verified_merge_blocks"] = len(order)
+    masters.close()
+    slaves.close()
+    return rec
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=2_900_000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--verify", type=int, default=24)
+    a = ap.parse_args()
+    import gam_ngs_amd as gam
+    print(json.dumps(run(gam.Context(0), genome=a.genome, steps=a.steps, seed=a.seed, verify=a.verify)))

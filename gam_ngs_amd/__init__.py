@@ -8,8 +8,8 @@ tests and the benchmark.  There is no CPU fallback: importing works anywhere (th
 without a GPU so its symbols can be checked), but creating a context without a gfx950 device raises.
 """
 from .lib import GamdpError, load_library, library_path  # noqa: F401
-from .api import (ABlast, BandedSmithWaterman, Block, Context, MergeBlock, MyAlignment, PctgBuilder,  # noqa: F401
-                  SequenceSet, GAP_A, GAP_B, MATCH, MISMATCH)
+from .api import (ABlast, BandedSmithWaterman, Block, Context, MergeBlock, MultiContext, MultiSequenceSet,  # noqa: F401
+                  MyAlignment, PctgBuilder, SequenceSet, GAP_A, GAP_B, MATCH, MISMATCH)
 
 __all__ = ["GamdpError", "load_library", "library_path", "Context", "SequenceSet", "BandedSmithWaterman",
-           "MyAlignment", "ABlast", "PctgBuilder", "MergeBlock", "Block", "GAP_A", "GAP_B", "MATCH", "MISMATCH"]
+           "MyAlignment", "ABlast", "MultiContext", "MultiSequenceSet", "PctgBuilder", "MergeBlock", "Block", "GAP_A", "GAP_B", "MATCH", "MISMATCH"]

@@ -85,15 +85,15 @@ class SequenceSet:
         return self
 
     @classmethod
-    def synthetic(cls, ctx: "Context", first_pair: int, n_pairs: int, length: int):
-        """Pairs [first_pair, first_pair+n_pairs) of the benchmark generator, built and packed inside the
+    def synthetic(cls, ctx: "Context", first_pair: int, n_pairs: int, length: int, stride: int = 1):
+        """Pairs first_pair + k*stride, k < n_pairs, of the benchmark generator, built and packed inside the
         library (sequence 2k = master, 2k+1 = slave); no host copy of the bases is kept."""
         self = cls.__new__(cls)
         self.ctx = ctx
         self._keep = []
         h = C.c_void_p()
-        _check(ctx, ctx.lib.gamdp_seqset_create_synth(ctx.handle, first_pair, n_pairs, length, C.byref(h)),
-               "gamdp_seqset_create_synth")
+        _check(ctx, ctx.lib.gamdp_seqset_create_synth_strided(ctx.handle, first_pair, stride, n_pairs, length, C.byref(h)),
+               "gamdp_seqset_create_synth_strided")
         self.handle = h
         self.lengths = [ctx.lib.gamdp_seqset_length(h, i) for i in range(2 * n_pairs)]
         return self
@@ -114,6 +114,89 @@ class SequenceSet:
             self.close()
         except Exception:
             pass
+
+
+class MultiContext:
+    """Several GPUs of one node behind one handle (gamdp_multi): the worker pool of ThreadedBuildPctg.cc:143-197.
+    `devices` may name a device more than once (one context each)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.lib = L.load_library()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.gamdp_multi_create(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise L.GamdpError("gamdp_multi_create(%r) failed with code %d; libgamdp has no CPU fallback" % (list(devices), rc))
+        self.handle = h
+        self.devices = list(devices)
+
+    def last_error(self):
+        return (self.lib.gamdp_multi_last_error(self.handle) or b"").decode()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gamdp_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiSequenceSet:
+    """The same contigs resident on every device of a MultiContext (gamdp_multi_seqset)."""
+
+    def __init__(self, mctx: MultiContext, seqs: Sequence[bytes], ascii: bool = True):
+        self.ctx = mctx
+        n = len(seqs)
+        self._keep = [bytes(s) for s in seqs]
+        arr = (C.c_char_p * max(1, n))(*self._keep)
+        lens = (C.c_uint64 * max(1, n))(*[len(s) for s in self._keep])
+        h = C.c_void_p()
+        rc = mctx.lib.gamdp_multi_seqset_create(mctx.handle, arr, lens, n, int(ascii), C.byref(h))
+        if rc != 0:
+            raise L.GamdpError("gamdp_multi_seqset_create failed with code %d: %s" % (rc, mctx.last_error()))
+        self.handle = h
+        self.lengths = [len(s) for s in self._keep]
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def contig(self, idx, rc=False, off=0):
+        return Contig(self, idx, rc, off)
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.gamdp_multi_seqset_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def partition_lpt(weights: Sequence[int], parts: int) -> List[int]:
+    """gamdp_partition_lpt: part of every item (deterministic longest-processing-time-first)."""
+    n = len(weights)
+    w = (C.c_uint64 * max(1, n))(*weights)
+    out = (C.c_uint32 * max(1, n))()
+    if L.load_library().gamdp_partition_lpt(w, n, parts, out) != 0:
+        raise L.GamdpError("gamdp_partition_lpt failed")
+    return list(out[:n])
+
+
+def task_preflight(alen, blen, band, begin_a, end_a, begin_b, end_b, fs=False, fe=False):
+    """(status, cells) the batch call settles on before launching anything (gamdp_task_preflight); status ST_OK means
+    the call needs the DP."""
+    m64 = (1 << 64) - 1
+    cells = C.c_uint64()
+    st = L.load_library().gamdp_task_preflight(alen, blen, band, begin_a & m64, end_a & m64, begin_b & m64, end_b & m64,
+                                               int(fs), int(fe), C.byref(cells))
+    return st, cells.value
 
 
 @dataclass(frozen=True)
@@ -224,9 +307,16 @@ class BandedSmithWaterman:
             offs_c = (C.c_uint64 * n)(*offs)
             caps_c = (C.c_uint64 * n)(*caps)
             ops_struct = L.Ops(C.cast(buf, C.c_void_p), offs_c, caps_c)
-        rc = self.ctx.lib.gamdp_align_batch(self.ctx.handle, sa.handle, sb.handle, tasks, n, out,
-                                            C.byref(ops_struct) if ops_struct else None)
-        _check(self.ctx, rc, "gamdp_align_batch")
+        if isinstance(self.ctx, MultiContext):
+            if want_ops:
+                raise L.GamdpError("edit strings are a single-context (test) feature")
+            rc = self.ctx.lib.gamdp_multi_align_batch(self.ctx.handle, sa.handle, sb.handle, tasks, n, out)
+            if rc != 0:
+                raise L.GamdpError("gamdp_multi_align_batch failed with code %d: %s" % (rc, self.ctx.last_error()))
+        else:
+            rc = self.ctx.lib.gamdp_align_batch(self.ctx.handle, sa.handle, sb.handle, tasks, n, out,
+                                                C.byref(ops_struct) if ops_struct else None)
+            _check(self.ctx, rc, "gamdp_align_batch")
         res = []
         for i in range(n):
             ops = None
@@ -370,9 +460,15 @@ class PctgBuilder:
             x.blocks = C.cast(arr, C.POINTER(L.BlockC))
         outs = (L.MbOut * n)()
         aud = (L.Result * (n * audit))() if audit else None
-        rc = self.ctx.lib.gamdp_align_merge_blocks(self.ctx.handle, self.masterRef.handle, self.slaveRef.handle, ins, n,
-                                                   self.band, outs, aud, audit)
-        _check(self.ctx, rc, "gamdp_align_merge_blocks")
+        if isinstance(self.ctx, MultiContext):
+            rc = self.ctx.lib.gamdp_multi_align_merge_blocks(self.ctx.handle, self.masterRef.handle, self.slaveRef.handle,
+                                                             ins, n, self.band, outs, aud, audit)
+            if rc != 0:
+                raise L.GamdpError("gamdp_multi_align_merge_blocks failed with code %d: %s" % (rc, self.ctx.last_error()))
+        else:
+            rc = self.ctx.lib.gamdp_align_merge_blocks(self.ctx.handle, self.masterRef.handle, self.slaveRef.handle, ins, n,
+                                                       self.band, outs, aud, audit)
+            _check(self.ctx, rc, "gamdp_align_merge_blocks")
         for i, mb in enumerate(mbs):
             o = outs[i]
             mb.align_ok, mb.status, mb.coords_set = bool(o.align_ok), o.status, bool(o.coords_set)

@@ -45,6 +45,14 @@ enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4,
              TF_NO_DIRFREE = 16 /* GAMDP_DIAG_NO_DIRFREE=1: keep directions in every block (A/B measurements) */,
              TF_DIAG_COUNT_MAT = 32 /* GAMDP_DIAG_COUNT_MAT=1: n_match := number of materialise() calls (results invalid) */ };
 
+// the diagnostics flags only exist in the -DGAMDP_DIAG build: the product kernels mask them off at compile time, so a
+// stray flag (or environment variable) can neither skip the traceback nor overwrite result fields with counters
+#ifdef GAMDP_DIAG
+constexpr u32 TF_LIVE_MASK = ~0u;
+#else
+constexpr u32 TF_LIVE_MASK = ~(u32)(TF_DIAG_SKIP_TRACEBACK | TF_NO_DIRFREE | TF_DIAG_COUNT_MAT);
+#endif
+
 struct DevResult {
     int32_t begin_a, begin_b;
     int32_t score;

@@ -32,6 +32,28 @@ namespace gamdp {
         }                                                                                         \
     } while (0)
 
+// ---- diagnostics switches ------------------------------------------------------------------------
+// The product build (libgamdp.so) ignores every GAMDP_DIAG_* environment variable except GAMDP_DIAG_TIMING (stderr
+// timing lines, results untouched).  The switches that change which kernel path runs, or that make results unusable,
+// exist only in the diagnostics build (`make diag` -> libgamdp_diag.so, compiled with -DGAMDP_DIAG), which tests and
+// profiling select through GAMDP_LIB.
+const Diag& diag()
+{
+    static const Diag d = [] {
+        Diag x;
+        x.timing = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
+#ifdef GAMDP_DIAG
+        x.build = true;
+        x.skip_traceback = std::getenv("GAMDP_DIAG_SKIP_TRACEBACK") != nullptr;
+        x.no_dirfree = std::getenv("GAMDP_DIAG_NO_DIRFREE") != nullptr;
+        x.count_mat = std::getenv("GAMDP_DIAG_COUNT_MAT") != nullptr;
+        x.force_n = std::getenv("GAMDP_DIAG_FORCE_N") != nullptr;
+#endif
+        return x;
+    }();
+    return d;
+}
+
 // ---- sequence packing ---------------------------------------------------------------------------
 
 static inline uint8_t encode_char(char ch)
@@ -72,7 +94,7 @@ int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, 
     u64 total = 0;
     std::vector<u64> at(n);
     for (u32 i = 0; i < n; i++) {
-        if (lens[i] >= (1ull << 31) - 3 * (u64)SEQ_PAD_BASES) return GAMDP_EINVAL;
+        if (lens[i] >= (1ull << 31) - (1ull << 20)) return GAMDP_EINVAL;  // keeps begin_a + X + 64*17 inside int32 in the kernels
         at[i] = total + SEQ_PAD_BASES;  // total stays a multiple of 64
         total += padded_bases(lens[i]);
     }
@@ -130,9 +152,9 @@ uint64_t synth_pair_codes(uint64_t k, uint64_t len, uint8_t* master, uint8_t* sl
 }
 }  // namespace
 
-// Benchmark helper: generate synthetic pairs [first_pair, first_pair + n_pairs) on host threads straight into the
+// Benchmark helper: generate synthetic pairs first_pair + k*stride_pairs, k < n_pairs, on host threads straight into the
 // packed planes (sequence 2k = master, 2k+1 = slave) and upload them; no 1 B/base host copy is kept.
-int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint32_t n_pairs, uint64_t len)
+int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint64_t stride_pairs, uint32_t n_pairs, uint64_t len)
 {
     ctx = ctx_;
     const u32 n = 2 * n_pairs;
@@ -152,7 +174,7 @@ int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint32_t n_pairs, uint6
             for (;;) {
                 const u32 k = cursor.fetch_add(1);
                 if (k >= n_pairs) break;
-                const u64 sl = synth_pair_codes(first_pair + k, len, m.data(), s.data());
+                const u64 sl = synth_pair_codes(first_pair + (u64)k * stride_pairs, len, m.data(), s.data());
                 lens[2 * k] = len;
                 lens[2 * k + 1] = sl;
                 // slots are 64-base aligned and disjoint, so threads never touch the same word
@@ -172,8 +194,10 @@ int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint32_t n_pairs, uint6
 }
 
 // make sure reverse-complement copies exist on the device for the listed sequence ids
-int SeqSet::ensure_rc(const std::vector<u32>& ids) const
+int SeqSet::ensure_rc(const std::vector<u32>& ids, Ctx* use) const
 {
+    std::lock_guard<std::mutex> lock(rc_mu);
+    Ctx* const ctx = use ? use : this->ctx;  // uploads go through the calling context's stream
     std::vector<u32> todo;
     for (u32 id : ids)
         if (!rc[id].p2 && std::find(todo.begin(), todo.end(), id) == todo.end()) todo.push_back(id);
@@ -189,8 +213,8 @@ int SeqSet::ensure_rc(const std::vector<u32>& ids) const
         pack_into(codes[todo[k]].data(), codes[todo[k]].size(), true, h2.data(), hn.data(), at[k]);
     u32 *p2 = nullptr, *pn = nullptr;
     HIPCHK(ctx, hipMalloc(&p2, h2.size() * sizeof(u32)));
+    rc_allocs.push_back(p2);  // owned from here on, whatever fails next
     HIPCHK(ctx, hipMalloc(&pn, hn.size() * sizeof(u32)));
-    rc_allocs.push_back(p2);
     rc_allocs.push_back(pn);
     HIPCHK(ctx, hipMemcpyAsync(p2, h2.data(), h2.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pn, hn.data(), hn.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
@@ -231,7 +255,9 @@ int Ctx::init(int dev)
 
 Ctx::~Ctx()
 {
+    for (Ctx* h : helpers) delete h;
     if (device >= 0) (void)hipSetDevice(device);
+    if (ref_event) (void)hipEventDestroy(ref_event);
     for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (d_scratch) (void)hipFree(d_scratch);
     if (d_tasks) (void)hipFree(d_tasks);
@@ -309,16 +335,14 @@ static void sort_by_key_desc(std::vector<u32>& ids, const std::vector<u64>& key)
     if (src != &ids) ids.swap(tmp);
 }
 
-// returns GAMDP_ST_OK when the task has to run on the GPU, otherwise its final status
-static int prepare_task(const ITask& it, Prepared& pr)
+// Validation in the order of banded_smith_waterman.cc:90-132 on plain numbers.  Returns GAMDP_ST_OK when the task has
+// to run on the GPU (then *X_out = rows of the band matrix), otherwise the final status the reference's behaviour maps
+// to; *cells_out = x_size * y_size whenever the reference got as far as sizing its matrix.
+int preflight(u64 alen, u64 blen, u64 band, u64 begin_a, u64 end_a, u64 begin_b, u64 end_b, bool fs, bool fe,
+              u64* X_out, u64* cells_out)
 {
-    const u64 alen_full = it.sa->lens[it.a_id], blen_full = it.sb->lens[it.b_id];
-    if (it.a_off > alen_full || it.b_off > blen_full) return GAMDP_ST_INVALID;
-    const u64 alen = alen_full - it.a_off, blen = blen_full - it.b_off;
-    const u64 band = it.band;
-    u64 begin_a = it.begin_a, end_a = it.end_a, begin_b = it.begin_b, end_b = it.end_b;
-    const bool fs = it.force_start, fe = it.force_end;
-    pr.cells = 0;
+    *X_out = 0;
+    *cells_out = 0;
     if (end_b < begin_b) return GAMDP_ST_EMPTY;                       // :90
     if (begin_a >= (1ull << 31) - 65536) return GAMDP_ST_INVALID;     // beyond any contig this code addresses
     const int64_t lo = std::max<int64_t>(0, (int64_t)begin_a - (int64_t)band), hi = (int64_t)begin_a + (int64_t)band;
@@ -336,14 +360,50 @@ static int prepare_task(const ITask& it, Prepared& pr)
     if (X > 500000) X = 500000;
     if (X == 0) return GAMDP_ST_INVALID;
     const u64 Y = 2 * band + 1;
-    pr.cells = X * Y;
+    *X_out = X;
+    *cells_out = X * Y;
     if (fs) {  // row 0 touches a.at(pos) for every 0 <= pos <= 10 in the band, even past |a| (:116)
         const int64_t up = std::min<int64_t>(hi, FORCE_MAXGAP_);
         if (lo <= up && up >= (int64_t)alen) return GAMDP_ST_OUT_OF_RANGE;
     }
-    // GAMDP_DIAG_FORCE_N (tests, profiling): run N-free inputs through the N-aware kernels as well
-    static const bool diag_force_n = std::getenv("GAMDP_DIAG_FORCE_N") != nullptr;
-    const bool has_n = diag_force_n || it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
+    if (begin_a > alen + band) {
+        // `lim` wrapped (the reference computes |a| + band - begin_a in unsigned long, :93-95): X is bounded by the b
+        // window alone and EVERY cell has pos >= |a|, so the matrix keeps its zeros and the fill does nothing.  The
+        // outcome follows from the end-cell scan (:174-212) alone: any eligible cell wins with value 0, lies outside a,
+        // and the traceback throws from a.at(pos); no eligible cell -> MyAlignment().  Resolved here: the kernels
+        // never see a window that starts past the padded contig.
+        bool found = false;
+        if (!fe) found = begin_a + (X - 1) - band <= end_a;                      // last row, column 0 has the smallest pos
+        {
+            const bool ge = end_a >= begin_a + band;
+            const int64_t i0 = ge ? (int64_t)(end_a - (begin_a + band)) : 0;
+            const int64_t j0 = ge ? (int64_t)(2 * band) : (int64_t)(2 * band) - (int64_t)(begin_a + band - end_a);
+            if (j0 >= 0 && (u64)i0 < X) {
+                const int64_t kmax = std::min<int64_t>((int64_t)X - 1 - i0, j0);  // cells (i0 + k, j0 - k), k = 0..kmax
+                if (!fe) found = true;
+                else if (X >= (u64)FORCE_MAXGAP_ + 1 && (u64)(i0 + kmax) >= X - 1 - (u64)FORCE_MAXGAP_) found = true;
+            }
+        }
+        return found ? GAMDP_ST_OUT_OF_RANGE : GAMDP_ST_EMPTY;
+    }
+    return GAMDP_ST_OK;
+}
+
+// returns GAMDP_ST_OK when the task has to run on the GPU, otherwise its final status
+static int prepare_task(const ITask& it, Prepared& pr)
+{
+    const u64 alen_full = it.sa->lens[it.a_id], blen_full = it.sb->lens[it.b_id];
+    pr.cells = 0;
+    if (it.a_off > alen_full || it.b_off > blen_full) return GAMDP_ST_INVALID;
+    const u64 alen = alen_full - it.a_off, blen = blen_full - it.b_off;
+    const u64 band = it.band;
+    const bool fs = it.force_start, fe = it.force_end;
+    u64 X = 0;
+    const int st = preflight(alen, blen, band, it.begin_a, it.end_a, it.begin_b, it.end_b, fs, fe, &X, &pr.cells);
+    if (st != GAMDP_ST_OK) return st;
+    const u64 Y = 2 * band + 1;
+    // GAMDP_DIAG_FORCE_N (diagnostics build only): run N-free inputs through the N-aware kernels as well
+    const bool has_n = diag().force_n || it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
     pr.kid = pick_kernel((int)band, has_n);
     const int C = kernel_cols(pr.kid);
     const int LE = (int)((Y - 1) / (u64)C);
@@ -354,9 +414,9 @@ static int prepare_task(const ITask& it, Prepared& pr)
     const DevSeq& db = it.b_rc ? it.sb->rc[it.b_id] : it.sb->fwd[it.b_id];
     d.a2 = da.p2; d.an = da.pn; d.b2 = db.p2; d.bn = db.pn;
     d.a_base = (int64_t)it.a_off; d.b_base = (int64_t)it.b_off;
-    d.end_a = (int64_t)std::min<u64>(end_a, 1ull << 40);
+    d.end_a = (int64_t)std::min<u64>(it.end_a, 1ull << 40);
     d.alen = (int32_t)alen; d.blen = (int32_t)blen;
-    d.begin_a = (int32_t)begin_a; d.begin_b = (int32_t)begin_b;
+    d.begin_a = (int32_t)it.begin_a; d.begin_b = (int32_t)it.begin_b;
     d.X = (int32_t)X; d.band = (int32_t)band;
     d.flags = (fs ? TF_FORCE_START : 0u) | (fe ? TF_FORCE_END : 0u);
     d.ops_off = 0; d.ops_cap = 0;
@@ -399,13 +459,11 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             if (t.a_rc) add(t.sa, t.a_id);
             if (t.b_rc) add(t.sb, t.b_id);
         }
-        for (auto& p : need) { int rc_ = p.first->ensure_rc(p.second); if (rc_) return rc_; }
+        for (auto& p : need) { int rc_ = p.first->ensure_rc(p.second, this); if (rc_) return rc_; }
     }
 
-    static const bool diag_skip_tb = std::getenv("GAMDP_DIAG_SKIP_TRACEBACK") != nullptr;
-    static const bool diag_timing = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
-    static const bool diag_no_dirfree = std::getenv("GAMDP_DIAG_NO_DIRFREE") != nullptr;
-    static const bool diag_count_mat = std::getenv("GAMDP_DIAG_COUNT_MAT") != nullptr;
+    const bool diag_skip_tb = diag().skip_traceback, diag_timing = diag().timing, diag_no_dirfree = diag().no_dirfree,
+               diag_count_mat = diag().count_mat;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     // per-batch work arrays live in the context: a fresh 50 MB vector per call costs more in page faults than the
@@ -422,7 +480,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         if (st != GAMDP_ST_OK) {
             std::memset(&out[i], 0, sizeof(out[i]));
             out[i].status = (uint8_t)st;
-            out[i].cells = (st == GAMDP_ST_OUT_OF_RANGE) ? prep[i].cells : 0;
+            out[i].cells = prep[i].cells;  // 0 unless the reference got as far as sizing its matrix
             continue;
         }
         prep[i].dt.res_idx = (u32)i;
@@ -576,6 +634,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
+            if (interval_sink && ref_event) {  // merge-block calls: where this launch sat on the call's time line
+                float t0 = 0;
+                if (hipEventElapsedTime(&t0, ref_event, events[li].first) == hipSuccess) interval_sink->push_back({t0, t0 + ms});
+            }
         }
         const auto t_fill = std::chrono::steady_clock::now();
         parallel_for(n_host_tasks, [&](size_t lo, size_t hi) {
@@ -693,6 +755,17 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     return c->align(it.data(), n, out, ops);
 }
 
+int gamdp_task_preflight(uint64_t alen, uint64_t blen, uint32_t band, uint64_t begin_a, uint64_t end_a, uint64_t begin_b,
+                         uint64_t end_b, int force_start, int force_end, uint64_t* cells)
+{
+    u64 X = 0, c = 0;
+    const int st = preflight(alen, blen, band, begin_a, end_a, begin_b, end_b, force_start != 0, force_end != 0, &X, &c);
+    if (cells) *cells = c;
+    return st;
+}
+
+unsigned gamdp_build_info(void) { return diag().build ? 1u : 0u; }
+
 void gamdp_encode(const char* chars, uint64_t n, uint8_t* codes)
 {
     for (uint64_t i = 0; i < n; i++) codes[i] = encode_char(chars[i]);
@@ -732,13 +805,19 @@ uint64_t gamdp_synth_pair(uint64_t k, uint64_t len, uint8_t* master, uint8_t* sl
 
 int gamdp_seqset_create_synth(gamdp_ctx* ctx, uint64_t first_pair, uint32_t n_pairs, uint64_t len, gamdp_seqset** out)
 {
+    return gamdp_seqset_create_synth_strided(ctx, first_pair, 1, n_pairs, len, out);
+}
+
+int gamdp_seqset_create_synth_strided(gamdp_ctx* ctx, uint64_t first_pair, uint64_t stride_pairs, uint32_t n_pairs, uint64_t len,
+                                      gamdp_seqset** out)
+{
     if (!ctx || !out || len == 0 || len >= (1ull << 30) || n_pairs >= (1u << 30)) return GAMDP_EINVAL;
     *out = nullptr;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (hipSetDevice(c->device) != hipSuccess) return GAMDP_EHIP;
     SeqSet* s = new (std::nothrow) SeqSet();
     if (!s) return GAMDP_ENOMEM;
-    const int rc_ = s->upload_synth(c, first_pair, n_pairs, len);
+    const int rc_ = s->upload_synth(c, first_pair, stride_pairs, n_pairs, len);
     if (rc_) { delete s; return rc_; }
     *out = reinterpret_cast<gamdp_seqset*>(s);
     return 0;

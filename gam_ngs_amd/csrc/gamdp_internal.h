@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -14,6 +15,17 @@ namespace gamdp {
 constexpr int64_t FORCE_MAXGAP_ = 10;  // FORCE_MAXGAP_LEN, banded_smith_waterman.hpp:37
 
 struct Ctx;
+
+// diagnostics switches (gamdp_host.cpp): all false in the product build except `timing`
+struct Diag {
+    bool build = false;  // compiled with -DGAMDP_DIAG
+    bool timing = false, skip_traceback = false, no_dirfree = false, count_mat = false, force_n = false;
+};
+const Diag& diag();
+
+// banded_smith_waterman.cc:90-132 on plain numbers: GAMDP_ST_OK = has to run on the GPU, else the final status
+int preflight(u64 alen, u64 blen, u64 band, u64 begin_a, u64 end_a, u64 begin_b, u64 end_b, bool fs, bool fe,
+              u64* X_out, u64* cells_out);
 
 struct DevSeq {
     u32* p2;  // word holding base 0 in the 2-bit plane
@@ -30,11 +42,12 @@ struct SeqSet {
     std::vector<DevSeq> fwd;
     mutable std::vector<DevSeq> rc;  // reverse complements, uploaded on first use
     mutable std::vector<u32*> rc_allocs;
+    mutable std::mutex rc_mu;        // the cohort threads of one merge-block call share a set (ensure_rc)
     u32 *d2 = nullptr, *dn = nullptr;
 
     int upload(Ctx* ctx, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, bool ascii);
-    int ensure_rc(const std::vector<u32>& ids) const;
-    int upload_synth(Ctx* ctx, uint64_t first_pair, uint32_t n_pairs, uint64_t len);
+    int ensure_rc(const std::vector<u32>& ids, Ctx* use = nullptr) const;
+    int upload_synth(Ctx* ctx, uint64_t first_pair, uint64_t stride_pairs, uint32_t n_pairs, uint64_t len);
     bool has_codes() const { return !codes.empty() || lens.empty(); }
     ~SeqSet();
 };
@@ -77,6 +90,12 @@ struct Ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double kernel_ms = 0;
     u64 kernel_launches = 0;
+    // merge-block calls: helper contexts on the same device (one per extra cohort thread, created on first use), the
+    // reference event kernel intervals are measured against, the intervals of the current call, its statistics
+    std::vector<Ctx*> helpers;
+    hipEvent_t ref_event = nullptr;
+    std::vector<std::pair<float, float>>* interval_sink = nullptr;
+    gamdp_l1_stats last_l1{};
 
     void set_error(const std::string& s) { err = s; }
     int init(int dev);
@@ -97,6 +116,9 @@ struct Fasta {
     std::vector<std::vector<uint8_t>> codes;
     std::string err;
 };
+
+// deterministic longest-processing-time-first partition (gamdp_multi.cpp)
+void partition_lpt(const u64* weights, size_t n, int parts, u32* part_of);
 
 // ABlast::findHits (ablast.cc:41-76) on code arrays
 void find_hits(const uint8_t* a, u64 alen, u64 a_start, u64 a_end, const uint8_t* b, u64 blen, u64 b_start, u64 b_end,

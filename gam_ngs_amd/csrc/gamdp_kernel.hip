@@ -88,7 +88,7 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
     if constexpr (DIRFREE_OK<CE, C, HASN>) {
         // the first run of fast blocks goes direction-free, in whole groups of 4 blocks, leaving at least one tagged
         // fast block in front (what a lane receives at a group start must be its neighbour's plain last column)
-        if (p.ckpt_off != 0 && !(dt.flags & TF_NO_DIRFREE)) {
+        if (p.ckpt_off != 0 && !(dt.flags & TF_LIVE_MASK & TF_NO_DIRFREE)) {
             int b0 = 0;
             while (b0 < nblk && mode_of(b0) != M_FAST) ++b0;
             int b1 = b0;

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <new>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -332,6 +334,46 @@ struct Machine {
 
 using namespace gamdp;
 
+namespace gamdp {
+namespace {
+
+struct CohortStats { int rounds = 0; double pending_ms = 0, align_ms = 0, feed_ms = 0; int rc = 0; };
+
+// The round loop over one cohort of merge blocks on one context (= one host thread + one stream): every round collects
+// the next pending find_alignment call of each unfinished machine into ONE L0 batch, feeds the results back and
+// advances the machines.  Cohorts run concurrently: while one waits for its kernel, another builds pending calls
+// (findHits over contig tails, descriptor preparation) or feeds results -- host work hides behind GPU work.
+void run_cohort(Ctx* c, std::vector<Machine>& M, const std::vector<u32>& ids, std::unordered_map<u32, std::vector<uint8_t>>& rc_cache,
+                std::mutex& rc_mu, CohortStats& st)
+{
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto msec = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::vector<ITask> tasks;
+    std::vector<u32> owner;
+    std::vector<gamdp_result> res;
+    for (;;) {
+        const auto t0 = now();
+        owner.clear();
+        for (u32 i : ids)
+            if (M[i].phase != Machine::DONE) owner.push_back(i);
+        if (owner.empty()) break;
+        tasks.assign(owner.size(), ITask{});
+        for (size_t q = 0; q < owner.size(); q++) M[owner[q]].pending(tasks[q], rc_cache, rc_mu);
+        const auto t1 = now();
+        res.assign(tasks.size(), gamdp_result{});
+        st.rc = c->align(tasks, res.data(), nullptr);
+        if (st.rc) return;
+        const auto t2 = now();
+        for (size_t q = 0; q < tasks.size(); q++) M[owner[q]].feed(res[q]);
+        const auto t3 = now();
+        st.pending_ms += msec(t0, t1); st.align_ms += msec(t1, t2); st.feed_ms += msec(t2, t3);
+        st.rounds++;
+    }
+}
+
+}  // namespace
+}  // namespace gamdp
+
 extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* master, const gamdp_seqset* slave,
                                         const gamdp_mb_in* in, size_t n, uint32_t band, gamdp_mb_out* out,
                                         gamdp_result* audit, uint32_t audit_stride)
@@ -341,7 +383,10 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     const SeqSet* ms = reinterpret_cast<const SeqSet*>(master);
     const SeqSet* ss = reinterpret_cast<const SeqSet*>(slave);
     if (band > GAMDP_MAX_BAND) { c->set_error("band exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->set_error("hipSetDevice failed"); return GAMDP_EHIP; }
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<Machine> M(n);
+    std::vector<u64> weight(n, 0);
     for (size_t i = 0; i < n; i++) {
         Machine& m = M[i];
         m.in = &in[i]; m.out = &out[i]; m.ms = ms; m.ss = ss; m.band = band;
@@ -354,51 +399,84 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         m.slen = ss->lens[in[i].s_id];
         if (audit) { m.audit = audit + i * (size_t)audit_stride; m.audit_cap = audit_stride; }
         m.init();
+        for (u32 k = 0; k < in[i].n_blocks && in[i].blocks; k++)
+            weight[i] += (u64)frame_len(in[i].blocks[k].s_begin, in[i].blocks[k].s_end) * (2ull * band + 1);
     }
+    // Cohorts: up to 4 host threads, each with its own context (stream, staging buffers, scratch arena) on this device,
+    // at least 48 merge blocks each; the merge blocks are dealt by predicted cells (LPT), so the cohorts' chains have
+    // similar depth.  Results do not depend on the split: every machine only sees its own results.
+    static const int max_cohorts = [] { const char* e = std::getenv("GAMDP_L1_COHORTS"); const int v = e ? std::atoi(e) : 4; return std::min(8, std::max(1, v)); }();
+    const int K = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_cohorts, n / 48));
+    while ((int)c->helpers.size() < K - 1) {
+        Ctx* h = new (std::nothrow) Ctx();
+        if (!h || h->init(c->device) != 0) { c->set_error("helper context: " + (h ? h->err : std::string("out of memory"))); delete h; return GAMDP_ENODEV; }
+        h->arena_limit = c->arena_limit;
+        c->helpers.push_back(h);
+    }
+    std::vector<u32> part(n, 0);
+    if (K > 1) partition_lpt(weight.data(), n, K, part.data());
+    std::vector<std::vector<u32>> ids((size_t)K);
+    for (size_t i = 0; i < n; i++) ids[part[i]].push_back((u32)i);
+
+    if (!c->ref_event && hipEventCreate(&c->ref_event) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
+    if (hipEventRecord(c->ref_event, c->stream) != hipSuccess || hipEventSynchronize(c->ref_event) != hipSuccess) { c->set_error("hipEventRecord failed"); return GAMDP_EHIP; }
+    std::vector<std::vector<std::pair<float, float>>> intervals((size_t)K);
+    std::vector<CohortStats> cst((size_t)K);
     std::unordered_map<u32, std::vector<uint8_t>> rc_cache;
     std::mutex rc_mu;
-    const size_t n_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    std::vector<ITask> tasks;
-    std::vector<size_t> owner;
-    std::vector<gamdp_result> res;
-    const bool diag = std::getenv("GAMDP_DIAG_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto msec = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    double t_pending = 0, t_align = 0, t_feed = 0;
-    int rounds = 0;
-    for (;;) {
-        const auto t0 = now();
-        owner.clear();
-        for (size_t i = 0; i < n; i++)
-            if (M[i].phase != Machine::DONE) owner.push_back(i);
-        if (owner.empty()) break;
-        tasks.assign(owner.size(), ITask{});
-        // building a pending call can involve a findHits over a contig tail: spread over the host cores,
-        // like the reference's worker threads (merge blocks are independent)
-        {
-            const size_t nt = std::min<size_t>(n_threads, (owner.size() + 63) / 64);
-            auto work = [&](size_t tid) {
-                for (size_t q = tid; q < owner.size(); q += nt) M[owner[q]].pending(tasks[q], rc_cache, rc_mu);
-            };
-            if (nt <= 1) work(0);
-            else {
-                std::vector<std::thread> th;
-                for (size_t tid = 0; tid < nt; tid++) th.emplace_back(work, tid);
-                for (auto& t : th) t.join();
-            }
-        }
-        const auto t1 = now();
-        res.assign(tasks.size(), gamdp_result{});
-        const int rc_ = c->align(tasks, res.data(), nullptr);
-        if (rc_) return rc_;
-        const auto t2 = now();
-        for (size_t q = 0; q < tasks.size(); q++) M[owner[q]].feed(res[q]);
-        const auto t3 = now();
-        t_pending += msec(t0, t1); t_align += msec(t1, t2); t_feed += msec(t2, t3);
-        rounds++;
+    const double k0_ms = c->kernel_ms; const u64 k0_n = c->kernel_launches;
+    auto body = [&](int k) {
+        Ctx* cc = k == 0 ? c : c->helpers[(size_t)k - 1];
+        if (k > 0) { cc->kernel_ms = 0; cc->kernel_launches = 0; cc->ref_event = c->ref_event; }
+        cc->interval_sink = &intervals[(size_t)k];
+        run_cohort(cc, M, ids[(size_t)k], rc_cache, rc_mu, cst[(size_t)k]);
+        cc->interval_sink = nullptr;
+        if (k > 0) cc->ref_event = nullptr;  // borrowed
+    };
+    if (K == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 1; k < K; k++) th.emplace_back(body, k);
+        body(0);
+        for (auto& t : th) t.join();
     }
-    if (diag)
-        std::fprintf(stderr, "gamdp_align_merge_blocks: %zu merge blocks, %d rounds: pending %.1f ms, align %.1f ms, feed %.1f ms\n",
-                     n, rounds, t_pending, t_align, t_feed);
+    for (int k = 0; k < K; k++)
+        if (cst[(size_t)k].rc) {
+            if (k > 0) c->set_error(c->helpers[(size_t)k - 1]->err);
+            return cst[(size_t)k].rc;
+        }
+    // statistics of this call; the helpers' kernel time is accounted to the caller's context
+    gamdp_l1_stats& S = c->last_l1;
+    S = gamdp_l1_stats{};
+    for (int k = 1; k < K; k++) { c->kernel_ms += c->helpers[(size_t)k - 1]->kernel_ms; c->kernel_launches += c->helpers[(size_t)k - 1]->kernel_launches; }
+    S.merge_blocks = n; S.cohorts = (uint32_t)K;
+    for (size_t i = 0; i < n; i++) { S.dp_calls += out[i].n_dp; S.cells += out[i].cells; }
+    std::vector<std::pair<float, float>> all;
+    for (int k = 0; k < K; k++) {
+        S.rounds = std::max<uint32_t>(S.rounds, (uint32_t)cst[(size_t)k].rounds);
+        S.host_pending_ms += cst[(size_t)k].pending_ms; S.host_feed_ms += cst[(size_t)k].feed_ms;
+        all.insert(all.end(), intervals[(size_t)k].begin(), intervals[(size_t)k].end());
+    }
+    S.launches = (uint32_t)(c->kernel_launches - k0_n);
+    S.kernel_sum_ms = c->kernel_ms - k0_ms;
+    std::sort(all.begin(), all.end());
+    float cur_lo = 0, cur_hi = -1;
+    for (auto& iv : all) {
+        if (cur_hi < cur_lo) { cur_lo = iv.first; cur_hi = iv.second; }
+        else if (iv.first <= cur_hi) cur_hi = std::max(cur_hi, iv.second);
+        else { S.gpu_busy_ms += cur_hi - cur_lo; cur_lo = iv.first; cur_hi = iv.second; }
+    }
+    if (cur_hi >= cur_lo) S.gpu_busy_ms += cur_hi - cur_lo;
+    S.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (gamdp::diag().timing)
+        std::fprintf(stderr, "gamdp_align_merge_blocks: %zu merge blocks, %d cohorts, %u rounds, %u launches: wall %.2f ms, GPU busy %.2f ms (kernels %.2f ms), pending %.2f ms, feed %.2f ms\n",
+                     n, K, S.rounds, S.launches, S.wall_ms, S.gpu_busy_ms, S.kernel_sum_ms, S.host_pending_ms, S.host_feed_ms);
+    return 0;
+}
+
+extern "C" int gamdp_ctx_l1_stats(const gamdp_ctx* ctx, gamdp_l1_stats* out)
+{
+    if (!ctx || !out) return GAMDP_EINVAL;
+    *out = reinterpret_cast<const Ctx*>(ctx)->last_l1;
     return 0;
 }

@@ -9,13 +9,17 @@ SYMBOLS = [
     "gamdp_ctx_create", "gamdp_ctx_destroy", "gamdp_ctx_set_arena_bytes", "gamdp_last_error", "gamdp_ctx_stream",
     "gamdp_ctx_kernel_time", "gamdp_seqset_create", "gamdp_seqset_destroy", "gamdp_seqset_size",
     "gamdp_seqset_length", "gamdp_align_batch", "gamdp_align_merge_blocks", "gamdp_find_hits", "gamdp_encode",
-    "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair", "gamdp_seqset_create_synth",
+    "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair", "gamdp_seqset_create_synth", "gamdp_seqset_create_synth_strided",
     "gamdp_fasta_open", "gamdp_fasta_close", "gamdp_fasta_count", "gamdp_fasta_name", "gamdp_fasta_codes",
     "gamdp_seqset_create_from_fasta",
     "gamdp_fasta_create", "gamdp_merge_lists_prepare", "gamdp_zscore_vote", "gamdp_pctgs_create", "gamdp_pctgs_destroy",
     "gamdp_pctgs_last_error", "gamdp_pctgs_add_graph", "gamdp_pctgs_finish", "gamdp_pctgs_count",
     "gamdp_pctgs_merged_count", "gamdp_pctgs_codes", "gamdp_pctgs_rows", "gamdp_pctgs_contig_use",
     "gamdp_pctgs_write_fasta", "gamdp_pctgs_write_descriptors",
+    "gamdp_task_preflight", "gamdp_build_info", "gamdp_ctx_l1_stats",
+    "gamdp_multi_create", "gamdp_multi_destroy", "gamdp_multi_size", "gamdp_multi_ctx", "gamdp_multi_last_error",
+    "gamdp_multi_seqset_create", "gamdp_multi_seqset_create_from_fasta", "gamdp_multi_seqset_destroy",
+    "gamdp_multi_seqset_on", "gamdp_multi_align_batch", "gamdp_multi_align_merge_blocks", "gamdp_partition_lpt",
     "gamdp_blocks_open", "gamdp_blocks_close", "gamdp_blocks_count", "gamdp_blocks_data", "gamdp_blocks_write",
 ]
 
@@ -65,6 +69,13 @@ class MbOut(C.Structure):
     _fields_ = [("align_ok", C.c_uint8), ("align_rev", C.c_uint8), ("status", C.c_uint8), ("coords_set", C.c_uint8),
                 ("m_start", C.c_int32), ("m_end", C.c_int32), ("s_start", C.c_int32), ("s_end", C.c_int32),
                 ("n_dp", C.c_uint32), ("cells", C.c_uint64)]
+
+
+class L1Stats(C.Structure):
+    _fields_ = [("merge_blocks", C.c_uint64), ("dp_calls", C.c_uint64), ("cells", C.c_uint64), ("rounds", C.c_uint32),
+                ("cohorts", C.c_uint32), ("launches", C.c_uint32), ("pad_", C.c_uint32), ("wall_ms", C.c_double),
+                ("gpu_busy_ms", C.c_double), ("kernel_sum_ms", C.c_double), ("host_pending_ms", C.c_double),
+                ("host_feed_ms", C.c_double)]
 
 
 class MBlock(C.Structure):
@@ -136,6 +147,28 @@ def load_library():
     lib.gamdp_align_batch.argtypes = [vp, vp, vp, C.POINTER(Task), C.c_size_t, C.POINTER(Result), C.POINTER(Ops)]
     lib.gamdp_align_merge_blocks.argtypes = [vp, vp, vp, C.POINTER(MbIn), C.c_size_t, u32, C.POINTER(MbOut),
                                              C.POINTER(Result), u32]
+    lib.gamdp_task_preflight.argtypes = [u64, u64, u32, u64, u64, u64, u64, C.c_int, C.c_int, C.POINTER(u64)]
+    lib.gamdp_ctx_l1_stats.argtypes = [vp, C.POINTER(L1Stats)]
+    lib.gamdp_build_info.argtypes = []
+    lib.gamdp_build_info.restype = C.c_uint
+    lib.gamdp_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.gamdp_multi_destroy.argtypes = [vp]
+    lib.gamdp_multi_destroy.restype = None
+    lib.gamdp_multi_size.argtypes = [vp]
+    lib.gamdp_multi_ctx.argtypes = [vp, C.c_int]
+    lib.gamdp_multi_ctx.restype = vp
+    lib.gamdp_multi_last_error.argtypes = [vp]
+    lib.gamdp_multi_last_error.restype = C.c_char_p
+    lib.gamdp_multi_seqset_create.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(vp)]
+    lib.gamdp_multi_seqset_create_from_fasta.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.gamdp_multi_seqset_destroy.argtypes = [vp]
+    lib.gamdp_multi_seqset_destroy.restype = None
+    lib.gamdp_multi_seqset_on.argtypes = [vp, C.c_int]
+    lib.gamdp_multi_seqset_on.restype = vp
+    lib.gamdp_multi_align_batch.argtypes = [vp, vp, vp, C.POINTER(Task), C.c_size_t, C.POINTER(Result)]
+    lib.gamdp_multi_align_merge_blocks.argtypes = [vp, vp, vp, C.POINTER(MbIn), C.c_size_t, u32, C.POINTER(MbOut),
+                                                   C.POINTER(Result), u32]
+    lib.gamdp_partition_lpt.argtypes = [C.POINTER(u64), C.c_size_t, C.c_int, C.POINTER(u32)]
     lib.gamdp_find_hits.argtypes = [C.c_char_p, u64, u64, u64, C.c_char_p, u64, u64, u64, u64, vp, u64]
     lib.gamdp_find_hits.restype = C.c_int64
     lib.gamdp_encode.argtypes = [C.c_char_p, u64, vp]
@@ -147,6 +180,7 @@ def load_library():
     lib.gamdp_synth_pair.argtypes = [u64, u64, vp, vp]
     lib.gamdp_synth_pair.restype = u64
     lib.gamdp_seqset_create_synth.argtypes = [vp, u64, u32, u64, C.POINTER(vp)]
+    lib.gamdp_seqset_create_synth_strided.argtypes = [vp, u64, u64, u32, u64, C.POINTER(vp)]
     lib.gamdp_fasta_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.gamdp_fasta_close.argtypes = [vp]
     lib.gamdp_fasta_close.restype = None

@@ -182,12 +182,68 @@ int gamdp_blocks_write(const char* path, const gamdp_block_rec* recs, uint64_t n
 int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seqset* set_b,
                       const gamdp_task* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops_or_null);
 
+/* What gamdp_align_batch decides for one call before anything is launched, on plain numbers (view lengths alen / blen):
+ * the checks of banded_smith_waterman.cc:90-132 in the reference's order.  Returns GAMDP_ST_OK when the call needs the
+ * DP (it would be launched), otherwise the final status (EMPTY / OUT_OF_RANGE / INVALID) the batch call reports without
+ * launching.  *cells (may be NULL) = x_size * y_size, the GCUPS unit and the weight the multi-GPU partitioner balances. */
+int gamdp_task_preflight(uint64_t alen, uint64_t blen, uint32_t band, uint64_t begin_a, uint64_t end_a, uint64_t begin_b,
+                         uint64_t end_b, int force_start, int force_end, uint64_t* cells);
+
+/* bit 0: this library is the diagnostics build (-DGAMDP_DIAG; honours the GAMDP_DIAG_* switches that change kernel
+ * paths or invalidate results).  The product build returns 0 and ignores those switches. */
+unsigned gamdp_build_info(void);
+
 /* ---- L1: batch of merge blocks ------------------------------------------------------------ */
 /* band is DEFAULT_BAND_SIZE (150) in the reference.  audit (optional) receives, per merge block i,
  * up to audit_stride results of its DP calls in call order at audit[i*audit_stride ...]. */
 int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* master, const gamdp_seqset* slave,
                              const gamdp_mb_in* in, size_t n, uint32_t band, gamdp_mb_out* out,
                              gamdp_result* audit, uint32_t audit_stride);
+
+/* What the last gamdp_align_merge_blocks call on this context did (timing of the driver itself). */
+typedef struct gamdp_l1_stats {
+    uint64_t merge_blocks, dp_calls, cells;
+    uint32_t rounds;          /* most rounds any cohort needed (a round = one batch of pending find_alignment calls) */
+    uint32_t cohorts;         /* host threads / streams the merge blocks were spread over on this device          */
+    uint32_t launches;        /* kernel launches                                                                   */
+    uint32_t pad_;
+    double wall_ms;           /* inside the call                                                                   */
+    double gpu_busy_ms;       /* union of the kernels' execution intervals (HIP events): time with >= 1 kernel running */
+    double kernel_sum_ms;     /* sum of the kernels' durations (can exceed gpu_busy_ms: cohorts overlap)          */
+    double host_pending_ms;   /* building pending calls incl. findHits, summed over cohort threads                 */
+    double host_feed_ms;      /* feeding results back, summed over cohort threads                                  */
+} gamdp_l1_stats;
+int gamdp_ctx_l1_stats(const gamdp_ctx* ctx, gamdp_l1_stats* out);
+
+/* ---- several GPUs of one node ------------------------------------------------------------- */
+/* Replaces gam-merge's worker pool (lib/src/pctg/ThreadedBuildPctg.cc:143-197: N pthreads, mutex-guarded cursor
+ * :50-74) for this path: one host thread + context + resident copy of the sequences per device; the task / merge-block
+ * list is partitioned statically (longest-processing-time first by predicted cell updates), every device fills the
+ * result slots of its own items, and nothing is exchanged between devices (no collective).  Results are identical to
+ * the single-context calls whatever the number of devices.  A device may be listed more than once (one context each). */
+typedef struct gamdp_multi gamdp_multi;
+typedef struct gamdp_multi_seqset gamdp_multi_seqset;
+int gamdp_multi_create(const int* devices, int n, gamdp_multi** out);
+void gamdp_multi_destroy(gamdp_multi* m);
+int gamdp_multi_size(const gamdp_multi* m);
+gamdp_ctx* gamdp_multi_ctx(gamdp_multi* m, int i);            /* borrowed: context of device slot i */
+const char* gamdp_multi_last_error(const gamdp_multi* m);
+/* the same sequences resident on every device (RefSequence is shared read-only by the reference's workers) */
+int gamdp_multi_seqset_create(gamdp_multi* m, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, int is_ascii,
+                              gamdp_multi_seqset** out);
+int gamdp_multi_seqset_create_from_fasta(gamdp_multi* m, const gamdp_fasta* f, gamdp_multi_seqset** out);
+void gamdp_multi_seqset_destroy(gamdp_multi_seqset* s);
+gamdp_seqset* gamdp_multi_seqset_on(gamdp_multi_seqset* s, int i);   /* borrowed: the copy on device slot i */
+/* gamdp_align_batch / gamdp_align_merge_blocks over all devices of m; out / audit are indexed like the input */
+int gamdp_multi_align_batch(gamdp_multi* m, const gamdp_multi_seqset* set_a, const gamdp_multi_seqset* set_b,
+                            const gamdp_task* tasks, size_t n, gamdp_result* out);
+int gamdp_multi_align_merge_blocks(gamdp_multi* m, const gamdp_multi_seqset* master, const gamdp_multi_seqset* slave,
+                                   const gamdp_mb_in* in, size_t n, uint32_t band, gamdp_mb_out* out, gamdp_result* audit,
+                                   uint32_t audit_stride);
+/* The partitioner on its own (host only): items in order of decreasing weight, ties by index, go to the least-loaded
+ * part, ties to the lower part.  Deterministic: the ranks of a one-process-per-GPU run (bench.py under
+ * torch.distributed.run) each derive the same assignment from it without communicating. */
+int gamdp_partition_lpt(const uint64_t* weights, size_t n, int parts, uint32_t* part_of);
 
 /* ---- host-side helpers on the path -------------------------------------------------------- */
 /* ABlast::findHits on code arrays; returns the number of hits (first cap written) or <0. */
@@ -283,6 +339,10 @@ uint64_t gamdp_synth_pair(uint64_t k, uint64_t len, uint8_t* master, uint8_t* sl
  * Such a set keeps no host copy of the bases: reverse-complement views and merge blocks are refused on it. */
 int gamdp_seqset_create_synth(gamdp_ctx* ctx, uint64_t first_pair, uint32_t n_pairs, uint64_t len,
                               gamdp_seqset** out);
+/* the same for pairs first_pair + k * stride_pairs, k < n_pairs: the share of one GPU when the fixed pair list of the
+ * benchmark is dealt round-robin over several (what gamdp_partition_lpt yields for equal weights) */
+int gamdp_seqset_create_synth_strided(gamdp_ctx* ctx, uint64_t first_pair, uint64_t stride_pairs, uint32_t n_pairs,
+                                      uint64_t len, gamdp_seqset** out);
 
 #ifdef __cplusplus
 }

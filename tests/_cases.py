@@ -82,3 +82,39 @@ def random_case(rng, max_len=300, bands=(0, 1, 2, 5, 8, 20, 150), windowed=True)
 def cases(seed, n, **kw):
     rng = random.Random(seed)
     return [random_case(rng, **kw) for _ in range(n)]
+
+
+def beyond_cases(seed, n, bands=(0, 1, 5, 20, 150), max_len=120):
+    """Windows whose begin_a lies at or past the end of a: begin_a in [|a|, |a| + band + rows + 8] and far past it
+    (the reference's `|a| + band - begin_a` wraps there, banded_smith_waterman.cc:93-95: the b window alone bounds the
+    rows and no cell is inside a).  The last sequence pair of a set gets these too, so a kernel that fetched there
+    would run off the allocation."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        la, lb = rng.randint(1, max_len), rng.randint(1, max_len)
+        a, b = rand_seq(rng, la, 0.03 if rng.random() < 0.3 else 0.0), rand_seq(rng, lb)
+        band = rng.choice(bands)
+        begin_b = rng.randint(0, lb - 1)
+        end_b = rng.randint(begin_b, lb + 3)
+        rows = min(end_b, lb - 1) - begin_b + 1
+        kind = rng.random()
+        if kind < 0.6:
+            begin_a = rng.randint(la, la + band + rows + 8)
+        elif kind < 0.8:
+            begin_a = la + band + rng.randint(-2, 2)
+        else:
+            begin_a = la + rng.choice([10 ** 4, 10 ** 6, 2 ** 30])
+        begin_a = max(0, begin_a)
+        k = rng.random()
+        if k < 0.3:
+            end_a = begin_a + rng.randint(0, 2 * band + rows + 4)
+        elif k < 0.6:
+            end_a = rng.randint(0, begin_a)
+        elif k < 0.8:
+            end_a = max(0, begin_a - band + rng.randint(-3, 3))
+        else:
+            end_a = la - 1
+        out.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=begin_a, end_a=end_a, begin_b=begin_b,
+                        end_b=end_b, fs=rng.random() < 0.3, fe=rng.random() < 0.4))
+    return out

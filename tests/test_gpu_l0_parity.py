@@ -16,6 +16,33 @@ from gam_ngs_amd import api
 
 pytestmark = pytest.mark.gpu
 
+# libgamdp_diag.so: same sources with -DGAMDP_DIAG (`make -C gam_ngs_amd/csrc diag`); the product library ignores the
+# GAMDP_DIAG_* switches these tests flip in child processes
+import os as _os
+DIAG_LIB = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gam_ngs_amd", "libgamdp_diag.so")
+
+
+def test_product_build_ignores_diagnostics_switches():
+    """The shipped library must not honour the result-invalidating switches: with them set in a child
+    process, a band-512 pair still comes back with its traceback done and bit-exact."""
+    import subprocess, sys
+    code = (
+        "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import random, _cases, _oracle as O\n"
+        "from _gpu import run_cases, oracle_for\n"
+        "import gam_ngs_amd as gam\n"
+        "assert gam.load_library().gamdp_build_info() == 0\n"
+        "a, b = _cases.related_pair(random.Random(5), 9000)\n"
+        "cs = dict(a=a.encode(), b=b.encode(), band=512, begin_a=0, end_a=len(a)-1, begin_b=0, end_b=len(b)-1, fs=False, fe=False)\n"
+        "r = run_cases([cs], want_ops=False)[0]; o, _ = oracle_for(cs, False)\n"
+        "assert r.key() == o.key() and o.status == 0 and o.length > 8000, (r.key(), o.key())\n"
+    ) % (_os.path.dirname(DIAG_LIB).rsplit("/", 1)[0], _os.path.dirname(_os.path.abspath(__file__)))
+    env = dict(_os.environ, GAMDP_DIAG_SKIP_TRACEBACK="1", GAMDP_DIAG_COUNT_MAT="1", GAMDP_DIAG_NO_DIRFREE="1",
+               GAMDP_DIAG_FORCE_N="1")
+    env.pop("GAMDP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
 
 def test_golden_small_cases_with_ops():
     items = G.l0_cases()
@@ -53,6 +80,24 @@ def test_random_cases_vs_oracle(seed):
             n_ok += o.status == O.OK
         assert not bad, bad[:3]
         assert n_ok > 200
+
+
+def test_begin_a_at_or_past_the_end_of_a():
+    """Windows that start at / past the end of a (the reference's row bound wraps, every cell lies outside a): resolved
+    on the host from the end-cell scan rules, never launched; the far-out ones sit on the LAST pair of the set."""
+    cases = _cases.beyond_cases(32, 1200, bands=(0, 1, 5, 20, 150, 512))
+    res = run_cases(cases, want_ops=False)
+    bad, stats = [], {}
+    for cs, r in zip(cases, res):
+        o, _ = oracle_for(cs, False)
+        if o.status == O.INVALID:
+            assert r.status == O.INVALID
+            continue
+        stats[o.status] = stats.get(o.status, 0) + 1
+        if r.key() != o.key():
+            bad.append((cs, r.key(), o.key()))
+    assert not bad, bad[:3]
+    assert stats.get(O.OUT_OF_RANGE, 0) > 50 and stats.get(O.EMPTY, 0) > 50, stats
 
 
 def test_medium_pairs_all_kernel_variants():
@@ -181,7 +226,7 @@ def test_n_aware_kernels_on_every_case_in_a_fresh_process():
     import os, subprocess, sys
     if os.environ.get("GAMDP_DIAG_FORCE_N"):
         pytest.skip("already inside the forced-N child")
-    env = dict(os.environ, GAMDP_DIAG_FORCE_N="1")
+    env = dict(os.environ, GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB)  # only the diagnostics build has the switch
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__),
                         "-k", "random_cases or medium_pairs or golden_large or row_cap"],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -223,7 +268,7 @@ def test_direction_free_fill_and_strip_materialisation():
             n_ok += o.status == 0
     assert n_ok >= 18
     if not os.environ.get("GAMDP_DIAG_NO_DIRFREE"):
-        env = dict(os.environ, GAMDP_DIAG_NO_DIRFREE="1")
+        env = dict(os.environ, GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
                             "direction_free or golden_large"], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

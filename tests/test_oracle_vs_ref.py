@@ -43,6 +43,15 @@ def test_out_of_range_cases_exist_and_match():
     assert n_oor >= 5
 
 
+def test_begin_a_at_or_past_the_end_of_a_matches_reference():
+    """begin_a >= |a| (up to far past it): the reference's row bound wraps; outcomes are EMPTY / OUT_OF_RANGE only"""
+    stats = {}
+    for c in _cases.beyond_cases(31, 1500):
+        s = check_case(c)
+        stats[s] = stats.get(s, 0) + 1
+    assert stats.get(O.OUT_OF_RANGE, 0) > 100 and stats.get(O.EMPTY, 0) > 100, stats
+
+
 def test_medium_pairs_band150_and_512():
     rng = random.Random(5)
     for n, band in ((3000, 150), (2500, 512), (4000, 20)):

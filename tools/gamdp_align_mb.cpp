@@ -1,8 +1,12 @@
 // gamdp-align-mb: run gam-merge's merge-block alignment step (PctgBuilder::alignMergeBlock for a whole list,
 // lib/src/pctg/BuildPctgFunctions.cc:82-84) on an MI355X from files, without the rest of gam-merge.
 //
-//   gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K]
-//                  [--pctgs PREFIX] [--vote master|slave|fail]
+//   gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D | --devices D0,D1,..]
+//                  [--repeat K] [--pctgs PREFIX] [--vote master|slave|fail]
+//
+// --devices runs the step on several GPUs of the node (gamdp_multi_*: merge blocks partitioned statically by predicted
+// cells, one host thread + context per device, no collective); a device may be listed twice.  The output is the same
+// whatever the device list -- unlike gam-merge --threads N, whose paired-contig order depends on thread timing.
 //
 // mergeblocks.tsv: one merge block per line, tab separated ('#' lines are comments):
 //   m_name s_name m_ltail m_rtail s_ltail s_rtail n_blocks  then n_blocks x (m_begin m_end s_begin s_end m_strand s_strand n_reads)
@@ -44,10 +48,17 @@ int main(int argc, char** argv)
                       "[--pctgs PREFIX] [--vote master|slave|fail]");
     unsigned band = GAMDP_DEFAULT_BAND;
     int device = 0, repeat = 1;
+    std::vector<int> devices;
     std::string pctg_prefix;
     for (int i = 5; i + 1 < argc; i += 2) {
         if (!std::strcmp(argv[i], "--band")) band = (unsigned)std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(argv[i + 1]);
+        else if (!std::strcmp(argv[i], "--devices")) {
+            std::stringstream ds(argv[i + 1]);
+            std::string tok;
+            while (std::getline(ds, tok, ',')) devices.push_back(std::atoi(tok.c_str()));
+            if (devices.empty()) die("--devices takes a comma-separated list");
+        }
         else if (!std::strcmp(argv[i], "--repeat")) repeat = std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--pctgs")) pctg_prefix = argv[i + 1];
         else if (!std::strcmp(argv[i], "--vote")) {
@@ -109,15 +120,24 @@ int main(int argc, char** argv)
     }
 
     gamdp_ctx* ctx = nullptr;
-    if (gamdp_ctx_create(device, &ctx)) die("no usable gfx950 GPU (libgamdp has no CPU fallback)");
+    gamdp_multi* multi = nullptr;
     gamdp_seqset *master = nullptr, *slave = nullptr;
-    if (gamdp_seqset_create_from_fasta(ctx, fm, &master) || gamdp_seqset_create_from_fasta(ctx, fs, &slave)) die(gamdp_last_error(ctx));
+    gamdp_multi_seqset *mmaster = nullptr, *mslave = nullptr;
+    if (devices.empty()) {
+        if (gamdp_ctx_create(device, &ctx)) die("no usable gfx950 GPU (libgamdp has no CPU fallback)");
+        if (gamdp_seqset_create_from_fasta(ctx, fm, &master) || gamdp_seqset_create_from_fasta(ctx, fs, &slave)) die(gamdp_last_error(ctx));
+    } else {
+        if (gamdp_multi_create(devices.data(), (int)devices.size(), &multi)) die("cannot open the listed gfx950 GPUs (libgamdp has no CPU fallback)");
+        if (gamdp_multi_seqset_create_from_fasta(multi, fm, &mmaster) || gamdp_multi_seqset_create_from_fasta(multi, fs, &mslave)) die(gamdp_multi_last_error(multi));
+    }
 
     std::vector<gamdp_mb_out> out(in.size());
     double best_s = 1e30;
     for (int r = 0; r < repeat; r++) {
         const auto t0 = std::chrono::steady_clock::now();
-        if (gamdp_align_merge_blocks(ctx, master, slave, in.data(), in.size(), band, out.data(), nullptr, 0)) die(gamdp_last_error(ctx));
+        if (multi) {
+            if (gamdp_multi_align_merge_blocks(multi, mmaster, mslave, in.data(), in.size(), band, out.data(), nullptr, 0)) die(gamdp_multi_last_error(multi));
+        } else if (gamdp_align_merge_blocks(ctx, master, slave, in.data(), in.size(), band, out.data(), nullptr, 0)) die(gamdp_last_error(ctx));
         best_s = std::min(best_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
 
@@ -173,6 +193,9 @@ int main(int argc, char** argv)
     }
     gamdp_seqset_destroy(master);
     gamdp_seqset_destroy(slave);
+    gamdp_multi_seqset_destroy(mmaster);
+    gamdp_multi_seqset_destroy(mslave);
+    gamdp_multi_destroy(multi);
     gamdp_ctx_destroy(ctx);
     gamdp_fasta_close(fm);
     gamdp_fasta_close(fs);
