@@ -496,11 +496,33 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         groups[prep[i].kid].push_back((u32)i);
     }
 
+    // Band 150 has two shapes: one task per wavefront (5 columns per lane: the lowest latency per task) and four tasks
+    // per wavefront (19 columns per lane, direction-free fill: ~1.7x the throughput).  A batch with more band-150 tasks
+    // than the chip has wave slots is throughput-bound and takes the second; merge-block rounds of a few hundred or
+    // thousand calls keep the first.  (GAMDP_QUAD_MIN overrides the threshold; results do not depend on it.)
+    {
+        static const long quad_min = [] { const char* e = std::getenv("GAMDP_QUAD_MIN"); return e ? std::atol(e) : -1L; }();
+        const size_t thr = quad_min >= 0 ? (size_t)quad_min : (size_t)n_cu * (size_t)kernel_waves_per_cu(0);
+        const int from[2] = {K_C5_CE0, K_C5_CE0_N}, to[2] = {K_Q19_CE15, K_Q19_CE15_N};
+        for (int v = 0; v < 2; v++) {
+            auto& g = groups[from[v]];
+            if (g.empty() || g.size() < std::max<size_t>(thr, 1)) continue;
+            const u64 C = (u64)kernel_cols(to[v]);
+            for (u32 i : g) {
+                const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
+                prep[i].kid = to[v];
+                prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1) * C * 64;
+            }
+            groups[to[v]] = std::move(g);
+            g.clear();
+        }
+    }
+
     const double ms_prep = since(t_begin);
-    int rc_ = grow(this, d_results, cap_results, n);
+    int rc_ = grow(this, d_results, cap_results, n + 1);  // + one dump slot for the padding tasks of the 4-task kernels
     if (rc_) return rc_;
     if (ops_total) { rc_ = grow(this, d_ops, cap_ops, ops_total); if (rc_) return rc_; }
-    rc_ = grow(this, d_tasks, cap_tasks, n);
+    rc_ = grow(this, d_tasks, cap_tasks, n + 256);
     if (rc_) return rc_;
 
     // arena budget
@@ -511,11 +533,11 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     }
 
     // pinned staging for the task upload and the result download (pageable copies cost ~20 ms per 60 k tasks)
-    if (n > cap_pinned) {
+    if (n + 256 > cap_pinned) {
         if (h_tasks) (void)hipHostFree(h_tasks);
         if (h_results) (void)hipHostFree(h_results);
         h_tasks = nullptr; h_results = nullptr; cap_pinned = 0;
-        const u64 want = n + n / 4;
+        const u64 want = n + n / 4 + 256;
         if (hipHostMalloc(&h_tasks, want * sizeof(DevTask)) != hipSuccess ||
             hipHostMalloc(&h_results, want * sizeof(DevResult)) != hipSuccess) {
             set_error("hipHostMalloc of staging buffers failed");
@@ -551,15 +573,16 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // the tuned N-free kernels fill their fast blocks without directions and keep, per 4 blocks, one live row
             // (C*64 words) and, per block, 512 boundary words instead (gamdp_kernel.hip, do_block_df)
             u64 ckpt_words = 0, bnd_words = 0;
-            if (kid == K_C17_CE4 || kid == K_C17_CE4_N) {
+            const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
+            if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
                 const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * cw;
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words();
             }
-            const u64 slotw = dirw + 4ull * ypad + ckpt_words + bnd_words;
+            const u64 slotw = dirw + 4ull * ypad * tpw + ckpt_words + bnd_words;
             const u64 fit = arena_limit / (slotw * sizeof(u32));
             if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
-            const u64 want = std::min<u64>(cur.size(), max_resident);
+            const u64 want = std::min<u64>((cur.size() + tpw - 1) / tpw, max_resident);
             if (fit < want && cur.size() > 1) {
                 std::vector<u32> big, small;
                 for (u32 i : cur) (prep[i].dir_words * 2 >= maxdir ? big : small).push_back(i);
@@ -570,15 +593,19 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 }
             }
             Launch L;
-            L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)cur.size();
+            const size_t padded = (cur.size() + tpw - 1) / tpw * tpw;
+            if (n_host_tasks + padded > n + 256) { set_error("too many 4-task launches in one batch"); return GAMDP_ENOMEM; }
+            L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)padded;
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
             L.n_slots = (u32)std::min<u64>(want, fit);
-            L.ckpt_off = ckpt_words ? dirw + 4ull * ypad : 0;
+            L.ckpt_off = ckpt_words ? dirw + 4ull * ypad * tpw : 0;
             L.bnd_off = L.ckpt_off + ckpt_words;
             {
                 DevTask* dst = h_tasks + n_host_tasks;
                 parallel_for(cur.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) dst[k] = prep[cur[k]].dt; });
-                n_host_tasks += cur.size();
+                // the last wavefront of a 4-task launch is filled up with copies of the last task that write to the dump slot
+                for (size_t k = cur.size(); k < padded; k++) { dst[k] = dst[cur.size() - 1]; dst[k].res_idx = (u32)n; dst[k].flags &= ~(u32)TF_WANT_OPS; }
+                n_host_tasks += padded;
             }
             launches.push_back(L);
         }
@@ -644,6 +671,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             for (size_t q = lo; q < hi; q++) {
                 const DevTask& d = h_tasks[q];
                 const u32 i = d.res_idx;
+                if (i >= n) continue;  // padding of a 4-task launch
                 fill_result(hres[i], prep[i].cells, out[i]);
                 if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
                     const u64 len = std::min<u64>(out[i].length, d.ops_cap);

@@ -36,6 +36,8 @@
 //   needed H values are spilled to small side buffers.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gamdp_dev.h"
 
 namespace gamdp {
@@ -144,6 +146,152 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align(const Launch
     }
 }
 
+// ---- four tasks per wavefront (throughput kernels of gam-merge's live band, 150) ---------------------------------
+// Band 150 is 301 columns: with one task per wavefront a lane owns 5 of them and the per-row work (operand reads, the
+// two hand-offs, the direction bookkeeping of the tagged cell) outweighs the cells.  Here a task takes one DPP row of 16
+// lanes x 19 columns (304 >= 301), four tasks step through their blocks in lock-step, and everything the band-512
+// kernels do applies: direction-free fast blocks (v_dot4 + v_max3 per cell), strips on demand, vectorised walk.  The four
+// tasks of a wavefront are neighbours in the launch's longest-first order, so they finish within a block or two of each
+// other; a task that is done sits masked through the slow END blocks of its companions.  One task per wavefront stays
+// the better shape when a batch has fewer tasks than the chip has wave slots (latency: 5 columns per lane and row-time
+// instead of 19), so the host picks per launch (gamdp_host.cpp).
+__device__ __forceinline__ int quad_or(int v)
+{
+    return __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int quad_max(int v)
+{
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int quad_min(int v)
+{
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int64_t rl64(int64_t v, int src)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)(u64)v, src), hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), src);
+    return (int64_t)(((u64)hi << 32) | lo);
+}
+template <class P>
+__device__ __forceinline__ P rlp(P p, int src) { return (P)(u64)rl64((int64_t)(u64)p, src); }
+// the values of the task held by lane `src`, in every lane
+__device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
+{
+    Tk t;
+    t.a2 = rlp(m.a2, src); t.an = rlp(m.an, src); t.b2 = rlp(m.b2, src); t.bn = rlp(m.bn, src);
+    t.a_base = rl64(m.a_base, src); t.b_base = rl64(m.b_base, src); t.end_a = rl64(m.end_a, src);
+    t.alen = __builtin_amdgcn_readlane(m.alen, src); t.blen = __builtin_amdgcn_readlane(m.blen, src);
+    t.begin_a = __builtin_amdgcn_readlane(m.begin_a, src); t.begin_b = __builtin_amdgcn_readlane(m.begin_b, src);
+    t.X = __builtin_amdgcn_readlane(m.X, src); t.band = __builtin_amdgcn_readlane(m.band, src); t.Y = __builtin_amdgcn_readlane(m.Y, src);
+    t.fs = __builtin_amdgcn_readlane((int)m.fs, src) != 0; t.fe = __builtin_amdgcn_readlane((int)m.fe, src) != 0;
+    t.iA = __builtin_amdgcn_readlane(m.iA, src); t.eaRel = __builtin_amdgcn_readlane(m.eaRel, src);
+    t.dir = rlp(m.dir, src); t.h0row = rlp(m.h0row, src); t.pos0 = rlp(m.pos0, src); t.lastrow = rlp(m.lastrow, src); t.adh = rlp(m.adh, src);
+    t.ckpt = rlp(m.ckpt, src); t.bnd = rlp(m.bnd, src);
+    t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src);
+    return t;
+}
+
+template <int C, int CE, bool HASN>
+__device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
+{
+    constexpr int LPT = QL;
+    static_assert(DIRFREE_OK<CE, C, HASN>, "the four-task kernels are direction-free kernels");
+    const int sub = lane >> 4;
+    const DevTask& dt = p.tasks[4 * qi + (u32)sub];  // every lane: the task of its DPP row
+    Tk t;
+    t.a2 = as_global(dt.a2); t.an = as_global(dt.an); t.b2 = as_global(dt.b2); t.bn = as_global(dt.bn);
+    t.a_base = dt.a_base; t.b_base = dt.b_base; t.end_a = dt.end_a;
+    t.alen = dt.alen; t.blen = dt.blen; t.begin_a = dt.begin_a; t.begin_b = dt.begin_b;
+    t.X = dt.X; t.band = dt.band; t.Y = 2 * dt.band + 1;
+    t.fs = dt.flags & TF_FORCE_START; t.fe = dt.flags & TF_FORCE_END;
+    t.dir = (gptr)slot;                                   // shared: [block][column group][wavefront lane]
+    t.h0row = (giptr)(slot + p.dir_words + (u64)sub * 4u * p.ypad);   // side buffers: one set per task
+    t.pos0 = t.h0row + p.ypad;
+    t.lastrow = t.pos0 + p.ypad;
+    t.adh = t.lastrow + p.ypad;
+    t.ckpt = (gptr)(slot + p.ckpt_off);
+    t.bnd = (gptr)(slot + p.bnd_off);
+    t.df_lo = t.df_hi = 0;
+    {
+        const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
+        t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
+        const bool ge = t.end_a >= (int64_t)t.begin_a + t.band;
+        const int64_t ia = ge ? t.end_a - ((int64_t)t.begin_a + t.band) : 0;
+        t.iA = (int)min(ia, (int64_t)(1 << 30));
+    }
+    const int X = t.X, w = t.band;
+    const int LE = (t.Y - 1) / C;
+    BlockState<C> st;
+    init_row0<C, HASN, true, LPT>(&st, &t, lane);
+
+    const int nblk = (X - 1 + LE) / ROWS + 1;      // of this lane's task
+    const int nblk_max = quad_max(nblk);
+    const int64_t iE0 = t.end_a - t.begin_a - w, iE1 = t.end_a - t.begin_a + w;
+    auto mode_of = [&](const int blk) {             // per lane: the mode its own task needs for this block
+        const int tau0 = blk * ROWS;
+        const bool top = !((tau0 - LE >= 1) && ((int64_t)t.begin_a - w + tau0 >= 1));
+        const bool end = !((tau0 + ROWS - 1 < X - 1) && ((int64_t)(tau0 + ROWS - 1) < iE0 || (int64_t)(tau0 - LE) > iE1));
+        return (top ? M_TOP : 0) | (end ? M_END : 0);
+    };
+    // direction-free range common to the four tasks: after every task's first fast block (+1 tagged one in front, see
+    // run_task), whole groups of 4 blocks, up to where the first task leaves its fast + end run
+    int e_min = 0;
+    if (p.ckpt_off != 0 && !(dt.flags & TF_LIVE_MASK & TF_NO_DIRFREE)) {
+        int b0 = 0;
+        while (b0 < nblk && mode_of(b0) != M_FAST) ++b0;
+        int b1 = b0;
+        while (b1 < nblk && mode_of(b1) == M_FAST) ++b1;
+        int b2 = b1;
+        while (b2 < nblk && mode_of(b2) == M_END) ++b2;
+        const int lo = quad_max((b0 + 1 + 3) & ~3), hi = quad_min(b2 & ~3);
+        e_min = quad_min(b1);
+        if (hi - lo >= 8 && e_min > lo) { t.df_lo = lo; t.df_hi = hi; }
+    }
+    const int df_lo = t.df_lo, df_hi = t.df_hi;  // wave-uniform by construction
+    for (int blk = 0; blk < nblk_max;) {
+        if (df_hi > df_lo && blk == df_lo) {
+            const int f_hi = min(df_hi, e_min);
+            if (f_hi > df_lo) fast_range<C, CE, HASN, true, false, LPT>(&st, &t, df_lo, f_hi, lane);
+            if (df_hi > f_hi) fast_range<C, CE, HASN, true, true, LPT>(&st, &t, max(f_hi, df_lo), df_hi, lane);
+            blk = df_hi;
+            continue;
+        }
+        const int m = quad_or(mode_of(blk));
+        if (m == M_FAST) {
+            const int limit = (df_hi > df_lo && blk < df_lo) ? df_lo : nblk_max;
+            int e = blk + 1;
+            while (e < limit && quad_or(mode_of(e)) == M_FAST) ++e;
+            fast_range<C, CE, HASN, false, false, LPT>(&st, &t, blk, e, lane);
+            blk = e;
+        } else {
+            if (m == M_TOP) slow_block<C, CE, HASN, M_TOP, LPT>(&st, &t, blk, lane);
+            else if (m == M_END) slow_block<C, CE, HASN, M_END, LPT>(&st, &t, blk, lane);
+            else slow_block<C, CE, HASN, M_BOTH, LPT>(&st, &t, blk, lane);
+            ++blk;
+        }
+    }
+    // end cell + walk: one task at a time, the whole wavefront on it
+#pragma unroll 1
+    for (int s4 = 0; s4 < QT; ++s4) {
+        const Tk ts = bcast_tk(t, QL * s4);
+        finish_task<C, CE, HASN, LPT>(&ts, &p.tasks[4 * qi + (u32)s4], &p, lane, QL * s4);
+    }
+}
+
+template <int C, int CE, bool HASN>
+__global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align_q(const LaunchParams p)
+{
+    const int lane = threadIdx.x;
+    u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
+    for (;;) {
+        u32 qi = 0;
+        if (lane == 0) qi = atomicAdd(p.cursor, 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (4 * qi >= p.n_tasks) break;   // n_tasks is a multiple of 4 (the host pads the last quad)
+        run_quad<C, CE, HASN>(p, qi, slot, lane);
+    }
+}
+
 }  // namespace
 
 int kernel_cols(int kid)
@@ -151,6 +299,7 @@ int kernel_cols(int kid)
     switch (kid) {
     case K_C17_CE4: case K_C17_CE4_N: case K_GEN_C17: return 17;
     case K_C5_CE0: case K_C5_CE0_N: case K_GEN_C5: return 5;
+    case K_Q19_CE15: case K_Q19_CE15_N: return 19;
     case K_GEN_C2: return 2;
     case K_GEN_C3: return 3;
     case K_GEN_C9: return 9;
@@ -159,6 +308,7 @@ int kernel_cols(int kid)
 }
 
 int kernel_waves_per_cu(int) { return 4 * GAMDP_WAVES_PER_SIMD; }
+int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : 1; }
 int kernel_bnd_words() { return (int)BND_WORDS; }
 
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
@@ -170,6 +320,8 @@ int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
     case K_C17_CE4_N: hipLaunchKernelGGL((k_align<17, 4, true>), g, b, 0, s, p); break;
     case K_C5_CE0:    hipLaunchKernelGGL((k_align<5, 0, false>), g, b, 0, s, p); break;
     case K_C5_CE0_N:  hipLaunchKernelGGL((k_align<5, 0, true>), g, b, 0, s, p); break;
+    case K_Q19_CE15:   hipLaunchKernelGGL((k_align_q<19, 15, false>), g, b, 0, s, p); break;
+    case K_Q19_CE15_N: hipLaunchKernelGGL((k_align_q<19, 15, true>), g, b, 0, s, p); break;
     case K_GEN_C2:    hipLaunchKernelGGL((k_align<2, -1, true>), g, b, 0, s, p); break;
     case K_GEN_C3:    hipLaunchKernelGGL((k_align<3, -1, true>), g, b, 0, s, p); break;
     case K_GEN_C5:    hipLaunchKernelGGL((k_align<5, -1, true>), g, b, 0, s, p); break;

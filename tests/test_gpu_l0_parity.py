@@ -233,6 +233,63 @@ def test_n_aware_kernels_on_every_case_in_a_fresh_process():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def band150_stress_cases():
+    """Band-150 cases for both kernel shapes (one task / four tasks per wavefront): pairs from 40 bases to 60 kb in one
+    batch (so the four tasks of a wavefront differ in length, top / end block ranges and direction-free range), drifting
+    paths, N runs, deep windows, force flags, unrelated sequences, windows past the end of a."""
+    rng = random.Random(150)
+    cases = []
+    for n, sub, ins, dele, nf in ((60000, 0.02, 0.01, 0.01, 0.0), (59000, 0.02, 0.02, 0.001, 0.0), (30000, 0.03, 0.001, 0.02, 0.0),
+                                  (30500, 0.0, 0.0, 0.0, 0.0), (12000, 0.03, 0.01, 0.01, 0.001), (12100, 0.03, 0.01, 0.01, 0.0),
+                                  (5000, 0.03, 0.01, 0.01, 0.0), (5010, 0.03, 0.01, 0.01, 0.0), (4990, 0.02, 0.0, 0.0, 0.01),
+                                  (2000, 0.03, 0.01, 0.01, 0.0), (700, 0.03, 0.01, 0.01, 0.0), (300, 0.05, 0.02, 0.02, 0.0),
+                                  (160, 0.0, 0.0, 0.0, 0.0), (40, 0.1, 0.0, 0.0, 0.0), (20000, 0.04, 0.012, 0.012, 0.0005)):
+        a = _cases.rand_seq(rng, n, nf)
+        b = _cases.mutate(rng, a, sub, ins, dele) or "A"
+        cases.append(dict(a=a.encode(), b=b.encode(), band=150, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    a = _cases.rand_seq(rng, 26000)
+    b = _cases.mutate(rng, a[3000:], 0.02, 0.01, 0.01)
+    for ba, ea, bb, eb, fs, fe in ((3000, len(a) - 1, 0, len(b) - 1, True, False), (2900, len(a) - 1, 0, len(b) - 1, False, True),
+                                   (3000, 14000, 0, len(b) - 1, False, False), (3100, len(a) + 100, 100, 20000, False, False),
+                                   (3000, len(a) - 1, 0, 6000, True, True), (0, len(a) - 1, 0, len(b) - 1, False, False)):
+        cases.append(dict(a=a.encode(), b=b.encode(), band=150, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb, fs=fs, fe=fe))
+    for _ in range(9):   # more short / medium pairs so that several wavefronts are mixed
+        n = rng.choice([90, 450, 1500, 3300, 8000])
+        a, b = _cases.related_pair(rng, n, n_frac=rng.choice([0.0, 0.0, 0.01]))
+        cases.append(dict(a=a.encode(), b=b.encode(), band=150, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    return cases
+
+
+def test_band150_stress_cases():
+    cases = band150_stress_cases()
+    n_ok = 0
+    for want_ops in (False, True):
+        res = run_cases(cases, want_ops=want_ops)
+        for k, (cs, r) in enumerate(zip(cases, res)):
+            o, ops = oracle_for(cs, want_ops)
+            assert r.key() == o.key(), (k, len(cs["a"]), r.key(), o.key())
+            if want_ops:
+                assert r.ops == ops, k
+            n_ok += o.status == 0
+    assert n_ok >= 50
+
+
+def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
+    """GAMDP_QUAD_MIN=1 sends every band-150 call of a batch through the throughput kernels (four tasks per wavefront,
+    16 lanes x 19 columns, direction-free fill) instead of only batches larger than the chip's wave slots: the band-150
+    cases of this file must come out bit-exact; a second child adds GAMDP_DIAG_FORCE_N (diagnostics build) for their
+    N-aware twin and a third switches the direction-free fill off."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_QUAD_MIN"):
+        pytest.skip("already inside the four-task child")
+    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap"
+    for extra in ({}, dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
+        env = dict(os.environ, GAMDP_QUAD_MIN="1", **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", sel],
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (extra, r.stdout[-2500:] + r.stderr[-2000:])
+
+
 def test_direction_free_fill_and_strip_materialisation():
     """Band 512 without N runs its fast blocks direction-free and re-creates the directions of a 4-lane strip around
     the path on demand (gamdp_kernel.hip: do_block_df / materialise).  Pairs built to stress that: indel-rich, with a
