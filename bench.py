@@ -108,15 +108,16 @@ def cpu_baseline(length, band, pair_ids):
     return rec, keys
 
 
-def kernel_name(band):
-    """The k_align instantiation the library picks for N-free contigs of this band (gamdp_host.cpp pick_kernel)."""
+def kernel_name(band, n_tasks=0):
+    """The kernel instantiation the library picks for N-free contigs of this band and batch size (gamdp_host.cpp)."""
     from gam_ngs_amd import lib as L
     forced_n = bool(os.environ.get("GAMDP_DIAG_FORCE_N")) and L.load_library().gamdp_build_info() & 1
     n = "true" if forced_n else "false"
     if band == 512:
         return "k_align<17,4,%s>" % n
     if band == 150:
-        return "k_align<5,0,%s>" % n
+        quad_min = int(os.environ.get("GAMDP_QUAD_MIN", "5120"))
+        return ("k_align_q<19,15,%s>" if n_tasks >= max(1, quad_min) else "k_align<5,0,%s>") % n
     y = 2 * band + 1
     c = next(c for c in (2, 3, 5, 9, 17) if y <= c * 64)
     return "k_align<%d,-1,true>" % c
@@ -292,7 +293,7 @@ def main():
                                             "workload, collected at commit %s), divided by this run's kernel time"
                                             % (traffic_src, traffic_commit or "unrecorded")) if traffic_src else None,
                          "algorithmic_bytes_per_launch": cells_per_launch * B_ALG,
-                         "kernel": kernel_name(args.band), "kernel_ms_per_launch": avg_launch_s * 1e3,
+                         "kernel": kernel_name(args.band, m["P"]), "kernel_ms_per_launch": avg_launch_s * 1e3,
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
         if weak is not None:

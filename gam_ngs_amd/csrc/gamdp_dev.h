@@ -94,7 +94,7 @@ int kernel_cols(int kid);
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream);
 // occupancy hint: resident waves per CU for this variant
 int kernel_waves_per_cu(int kid);
-int kernel_bnd_words();  // boundary words per block of the direction-free kernels
+int kernel_bnd_words(int kid);  // boundary words per block of the direction-free kernels
 int kernel_tasks_per_wave(int kid);  // 4 for the K_Q* variants (their task list is padded to a multiple of 4), else 1
 
 }  // namespace gamdp

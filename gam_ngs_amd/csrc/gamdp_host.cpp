@@ -577,7 +577,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
                 const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * cw;
-                bnd_words = (nblk + 4) * (u64)kernel_bnd_words();
+                bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);
             }
             const u64 slotw = dirw + 4ull * ypad * tpw + ckpt_words + bnd_words;
             const u64 fit = arena_limit / (slotw * sizeof(u32));

@@ -309,7 +309,8 @@ int kernel_cols(int kid)
 
 int kernel_waves_per_cu(int) { return 4 * GAMDP_WAVES_PER_SIMD; }
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : 1; }
-int kernel_bnd_words() { return (int)BND_WORDS; }
+
+int kernel_bnd_words(int kid) { return kernel_tasks_per_wave(kid) > 1 ? (int)Strip<QL>::BND_WORDS : (int)Strip<64>::BND_WORDS; }
 
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
 {
