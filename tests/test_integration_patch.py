@@ -1,0 +1,57 @@
+"""integration/gam-merge-gamdp.patch: the adapter for the real gam-merge.
+
+* The bridge translation unit -- the only file of the patch that calls the C ABI -- compiles against include/gamdp.h
+  in isolation (it is free of GAM-NGS / Boost types on purpose).
+* Where the reference tree is available (the build container, not the GPU box): the patch applies cleanly to a copy
+  of it, the new files it adds are the master copies under integration/, and the patched tree's bridge compiles.
+The patched gam-merge cannot be linked here (Boost, sparsehash absent): applying + type-checking is the bar."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+PATCH = os.path.join(ROOT, "integration", "gam-merge-gamdp.patch")
+
+
+def test_bridge_compiles_against_the_c_abi_alone(tmp_path):
+    inc = tmp_path / "inc" / "pctg"
+    inc.mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "integration", "GamdpBridge.hpp"), inc)
+    for std in ("gnu++98", "gnu++17"):   # the reference is C++98-style code that also builds as C++17
+        r = subprocess.run(["g++", "-std=" + std, "-Wall", "-Wextra", "-Werror", "-c", "-I" + os.path.join(ROOT, "include"),
+                            "-I" + str(tmp_path / "inc"), os.path.join(ROOT, "integration", "GamdpBridge.cc"), "-o",
+                            str(tmp_path / "bridge.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    # every gamdp_* symbol the bridge uses is exported by the library
+    nm = subprocess.run(["nm", "-u", str(tmp_path / "bridge.o")], capture_output=True, text=True).stdout
+    used = sorted(set(l.split()[-1] for l in nm.splitlines() if " gamdp_" in l))
+    assert "gamdp_multi_align_merge_blocks" in used and "gamdp_multi_seqset_create" in used
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "gam_ngs_amd", "libgamdp.so"))
+    for name in used:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "lib", "src", "pctg")), reason="reference tree not present")
+def test_patch_applies_cleanly_to_the_reference(tmp_path):
+    tree = tmp_path / "gam-ngs"
+    shutil.copytree(REF, tree, ignore=shutil.ignore_patterns(".git", "bamtools-2.3.0"))
+    dry = subprocess.run(["patch", "-p1", "--dry-run", "-i", PATCH], cwd=tree, capture_output=True, text=True)
+    assert dry.returncode == 0 and "FAILED" not in dry.stdout and "fuzz" not in dry.stdout, dry.stdout + dry.stderr
+    real = subprocess.run(["patch", "-p1", "-i", PATCH], cwd=tree, capture_output=True, text=True)
+    assert real.returncode == 0, real.stdout + real.stderr
+    for rel, master in (("lib/include/pctg/GamdpBridge.hpp", "GamdpBridge.hpp"), ("lib/src/pctg/GamdpBridge.cc", "GamdpBridge.cc")):
+        assert open(tree / rel).read() == open(os.path.join(ROOT, "integration", master)).read(), rel
+    r = subprocess.run(["g++", "-std=gnu++11", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-Ilib/include",
+                        "lib/src/pctg/GamdpBridge.cc"], cwd=tree, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the seam and the three-phase run are where the patch says they are
+    bf = open(tree / "lib/src/pctg/BuildPctgFunctions.cc").read()
+    assert "builder.alignMergeBlock(graph,*mb);" in bf and "prepareMergeLists" in bf and "finishPctg" in bf
+    tb = open(tree / "lib/src/pctg/ThreadedBuildPctg.cc").read()
+    assert "ThreadedBuildPctg::runOnGpu()" in tb and "if( gamdp_bridge::ready() ) return this->runOnGpu();" in tb
+    assert "gamdp_bridge::init( masterCodes, slaveCodes );" in open(tree / "src/Merge.cc").read()
+    assert "GamdpBridge.cc" in open(tree / "CMakeLists.txt").read()
