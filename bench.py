@@ -114,6 +114,8 @@ def kernel_name(band, n_tasks=0):
     forced_n = bool(os.environ.get("GAMDP_DIAG_FORCE_N")) and L.load_library().gamdp_build_info() & 1
     n = "true" if forced_n else "false"
     if band == 512:
+        if n == "false" and n_tasks >= 2 and not os.environ.get("GAMDP_NO_PAIR"):
+            return "k_align_p<17,4>"      # two tasks per wavefront, fast blocks in packed f16
         return "k_align<17,4,%s>" % n
     if band == 150:
         quad_min = int(os.environ.get("GAMDP_QUAD_MIN", "5120"))
@@ -123,7 +125,7 @@ def kernel_name(band, n_tasks=0):
     return "k_align<%d,-1,true>" % c
 
 
-def measured_traffic(P_launch, length, band, launches_ok):
+def measured_traffic(P_launch, length, band, launches_ok, kernel):
     """HBM bytes per launch from the PMC counters.  FETCH_SIZE / WRITE_SIZE need their own rocprofv3 passes, so the
     figure is REPLAYED from the newest committed profile of exactly this workload (its file and the commit it was
     collected on are named in the line); null when the workload differs or no profile exists."""
@@ -134,7 +136,8 @@ def measured_traffic(P_launch, length, band, launches_ok):
             try:
                 tj = json.load(open(os.path.join(pdir, name)))
                 w = tj["workload"]
-                if (w["pairs_per_launch"], w["len"], w["band"]) == (P_launch, length, band) and launches_ok:
+                same_kernel = kernel.replace(" ", "").split("<")[0] + "<" in tj.get("kernel", "").replace(" ", "")
+                if (w["pairs_per_launch"], w["len"], w["band"]) == (P_launch, length, band) and launches_ok and same_kernel:
                     best = (name, tj)
             except (OSError, KeyError, ValueError):
                 pass
@@ -271,7 +274,8 @@ def main():
         avg_launch_s = (m["kernel_ms"] / 1e3) / max(1, launches)
         cells_per_launch = m["cells_rank"] * steps / max(1, launches)
         achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic_bytes, traffic_src, traffic_commit = measured_traffic(m["P"], length, band, launches == steps)
+        kname = kernel_name(args.band, m["P"])
+        traffic_bytes, traffic_src, traffic_commit = measured_traffic(m["P"], length, band, launches == steps, kname)
         line = {
             "metric": "GCUPS", "value": m["gcups"], "unit": "GCUPS", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": m["dt_max"] / steps * 1e3, "higher_is_better": True,
@@ -293,7 +297,7 @@ def main():
                                             "workload, collected at commit %s), divided by this run's kernel time"
                                             % (traffic_src, traffic_commit or "unrecorded")) if traffic_src else None,
                          "algorithmic_bytes_per_launch": cells_per_launch * B_ALG,
-                         "kernel": kernel_name(args.band, m["P"]), "kernel_ms_per_launch": avg_launch_s * 1e3,
+                         "kernel": kname, "kernel_ms_per_launch": avg_launch_s * 1e3,
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
         }
         if weak is not None:

@@ -83,6 +83,7 @@ enum KernelId : int {
     K_C17_CE4_N,     // band 512, N-aware
     K_C5_CE0,        // band 150 (gam-merge's live default), ACGT only
     K_C5_CE0_N,      // band 150, N-aware
+    K_P17_CE4,       // band 512, ACGT only, TWO tasks per wavefront, fast blocks in packed f16 (kernel_pair.inc)
     K_Q19_CE15,      // band 150, ACGT only, FOUR tasks per wavefront (16 lanes x 19 columns each): big batches
     K_Q19_CE15_N,    // the same, N-aware
     K_GEN_C2, K_GEN_C3, K_GEN_C5, K_GEN_C9, K_GEN_C17,  // any band, N-aware, runtime edge column
@@ -95,6 +96,7 @@ int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
 // occupancy hint: resident waves per CU for this variant
 int kernel_waves_per_cu(int kid);
 int kernel_bnd_words(int kid);  // boundary words per block of the direction-free kernels
+int kernel_ckpt_words(int kid);      // words per group (4 blocks) of the live-row store of the direction-free kernels
 int kernel_tasks_per_wave(int kid);  // 4 for the K_Q* variants (their task list is padded to a multiple of 4), else 1
 
 }  // namespace gamdp

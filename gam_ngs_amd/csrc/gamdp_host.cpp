@@ -518,6 +518,19 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         }
     }
 
+    // Band 512 without N: two tasks per wavefront, their common fast blocks in packed f16 (kernel_pair.inc) -- whenever
+    // there are two tasks to pair.  (GAMDP_NO_PAIR=1 keeps the one-task kernel: A/B measurements; results do not
+    // depend on it.  The diagnostics switch that keeps a direction per cell also does.)
+    {
+        static const bool no_pair = std::getenv("GAMDP_NO_PAIR") != nullptr;
+        auto& g = groups[K_C17_CE4];
+        if (!no_pair && !diag_no_dirfree && g.size() >= 2) {
+            for (u32 i : g) prep[i].kid = K_P17_CE4;   // same C and LE: dir_words stay
+            groups[K_P17_CE4] = std::move(g);
+            g.clear();
+        }
+    }
+
     const double ms_prep = since(t_begin);
     int rc_ = grow(this, d_results, cap_results, n + 1);  // + one dump slot for the padding tasks of the 4-task kernels
     if (rc_) return rc_;
@@ -529,7 +542,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     if (arena_limit == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(this, hipMemGetInfo(&fr, &tot));
-        arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.6);
+        arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.75);
     }
 
     // pinned staging for the task upload and the result download (pageable copies cost ~20 ms per 60 k tasks)
@@ -550,10 +563,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots; u64 ckpt_off, bnd_off; };
     std::vector<Launch> launches;
-    const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(0);
     for (int kid = 0; kid < K_COUNT; kid++) {
         auto& g = groups[kid];
         if (g.empty()) continue;
+        const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(kid);
         sort_by_key_desc(g, cells_key);  // longest tasks first (LPT); ties keep the caller's order
         // One launch per group if slots sized for its largest direction matrix leave enough resident
         // waves; otherwise peel off the tasks with big matrices into their own launch and retry.
@@ -574,12 +587,14 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // (C*64 words) and, per block, 512 boundary words instead (gamdp_kernel.hip, do_block_df)
             u64 ckpt_words = 0, bnd_words = 0;
             const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
+            const bool pair = kid == K_P17_CE4;               // ... and, for the pairs, its own direction words
             if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
                 const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
-                ckpt_words = (nblk / 4 + 2) * cw;
+                ckpt_words = (nblk / 4 + 2) * (u64)kernel_ckpt_words(kid);
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);
             }
-            const u64 slotw = dirw + 4ull * ypad * tpw + ckpt_words + bnd_words;
+            const u64 dir_total = pair ? 2 * dirw : dirw;
+            const u64 slotw = dir_total + 4ull * ypad * tpw + ckpt_words + bnd_words;
             const u64 fit = arena_limit / (slotw * sizeof(u32));
             if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
             const u64 want = std::min<u64>((cur.size() + tpw - 1) / tpw, max_resident);
@@ -598,7 +613,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)padded;
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
             L.n_slots = (u32)std::min<u64>(want, fit);
-            L.ckpt_off = ckpt_words ? dirw + 4ull * ypad * tpw : 0;
+            L.ckpt_off = ckpt_words ? dir_total + 4ull * ypad * tpw : 0;
             L.bnd_off = L.ckpt_off + ckpt_words;
             {
                 DevTask* dst = h_tasks + n_host_tasks;

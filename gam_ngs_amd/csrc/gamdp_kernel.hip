@@ -45,6 +45,7 @@ namespace {
 
 #include "kernel_common.inc"
 #include "kernel_fill.inc"
+#include "kernel_pair.inc"
 #include "kernel_strip.inc"
 #include "kernel_finish.inc"
 
@@ -143,6 +144,129 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align(const Launch
         ti = __builtin_amdgcn_readfirstlane(ti);
         if (ti >= p.n_tasks) break;
         run_task<C, CE, HASN>(p.tasks[ti], p, slot, lane);
+    }
+}
+
+// ---- two tasks per wavefront, fast blocks in packed f16 (kernel_pair.inc) -------------------------------------------
+__device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, u32* dir, u32* side, u32* slot)
+{
+    Tk t;
+    t.a2 = as_global(dt.a2); t.an = as_global(dt.an); t.b2 = as_global(dt.b2); t.bn = as_global(dt.bn);
+    t.a_base = dt.a_base; t.b_base = dt.b_base; t.end_a = dt.end_a;
+    t.alen = dt.alen; t.blen = dt.blen; t.begin_a = dt.begin_a; t.begin_b = dt.begin_b;
+    t.X = dt.X; t.band = dt.band; t.Y = 2 * dt.band + 1;
+    t.fs = dt.flags & TF_FORCE_START; t.fe = dt.flags & TF_FORCE_END;
+    t.dir = (gptr)dir;
+    t.h0row = (giptr)side;
+    t.pos0 = t.h0row + p.ypad;
+    t.lastrow = t.pos0 + p.ypad;
+    t.adh = t.lastrow + p.ypad;
+    t.ckpt = (gptr)(slot + p.ckpt_off);
+    t.bnd = (gptr)(slot + p.bnd_off);
+    t.df_lo = t.df_hi = 0;
+    const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
+    t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
+    const bool ge = t.end_a >= (int64_t)t.begin_a + t.band;
+    const int64_t ia = ge ? t.end_a - ((int64_t)t.begin_a + t.band) : 0;
+    t.iA = (int)min(ia, (int64_t)(1 << 30));
+    return t;
+}
+
+// block modes of one task (scalar) and its runs: b0 = first fast block, b1 = first block after that fast run
+struct Plan { int nblk, b0, b1; int64_t iE0, iE1; int X, LE, begin_a, w; };
+__device__ __forceinline__ int plan_mode(const Plan& pl, const int blk)
+{
+    const int tau0 = blk * ROWS;
+    const bool top = !((tau0 - pl.LE >= 1) && ((int64_t)pl.begin_a - pl.w + tau0 >= 1));
+    const bool end = !((tau0 + ROWS - 1 < pl.X - 1) && ((int64_t)(tau0 + ROWS - 1) < pl.iE0 || (int64_t)(tau0 - pl.LE) > pl.iE1));
+    return (top ? M_TOP : 0) | (end ? M_END : 0);
+}
+template <int C>
+__device__ __forceinline__ Plan make_plan(const Tk& t)
+{
+    Plan pl;
+    pl.X = t.X; pl.w = t.band; pl.begin_a = t.begin_a; pl.LE = (t.Y - 1) / C;
+    pl.nblk = (t.X - 1 + pl.LE) / ROWS + 1;
+    pl.iE0 = t.end_a - t.begin_a - t.band; pl.iE1 = t.end_a - t.begin_a + t.band;
+    int b0 = 0;
+    while (b0 < pl.nblk && plan_mode(pl, b0) != M_FAST) ++b0;
+    int b1 = b0;
+    while (b1 < pl.nblk && plan_mode(pl, b1) == M_FAST) ++b1;
+    pl.b0 = b0; pl.b1 = b1;
+    return pl;
+}
+
+// blocks [from, to) of one task with the int32 tagged code (directions for every cell)
+template <int C, int CE, bool HASN>
+__device__ __forceinline__ void tagged_blocks(BlockState<C>* st, const Tk* t, const Plan& pl, const int from, const int to, const int lane)
+{
+    for (int blk = from; blk < to;) {
+        const int m = plan_mode(pl, blk);
+        if (m == M_FAST) {
+            int e = blk + 1;
+            while (e < to && plan_mode(pl, e) == M_FAST) ++e;
+            fast_range<C, CE, HASN, false>(st, t, blk, e, lane);
+            blk = e;
+        } else {
+            if (m == M_TOP) slow_block<C, CE, HASN, M_TOP>(st, t, blk, lane);
+            else if (m == M_END) slow_block<C, CE, HASN, M_END>(st, t, blk, lane);
+            else slow_block<C, CE, HASN, M_BOTH>(st, t, blk, lane);
+            ++blk;
+        }
+    }
+}
+
+template <int C, int CE>
+__device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
+{
+    constexpr bool HASN = false;
+    const DevTask& da = p.tasks[2 * qi];
+    const DevTask& db = p.tasks[2 * qi + 1];
+    // slot: [dir A][dir B][side buffers A][side buffers B][packed rows][packed boundaries]
+    u32* const sideA = slot + 2 * p.dir_words;
+    Tk ta = make_tk(da, p, slot, sideA, slot);
+    Tk tb = make_tk(db, p, slot + p.dir_words, sideA + 4u * p.ypad, slot);
+    const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);
+    // the packed range: fast blocks of BOTH tasks, whole groups of 4 blocks, at least one tagged fast block in front of it
+    // for either task (what a lane receives at a group start must be its neighbour's plain last column)
+    int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, hi = min(pa.b1, pb.b1) & ~3;
+    if (!(p.ckpt_off != 0 && hi - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = hi = 0;
+    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    BlockState<C> sta, stb;
+    init_row0<C, HASN, true>(&sta, &ta, lane);
+    tagged_blocks<C, CE, HASN>(&sta, &ta, pa, 0, hi > lo ? lo : pa.nblk, lane);
+    init_row0<C, HASN, true>(&stb, &tb, lane);
+    tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : pb.nblk, lane);
+    if (hi > lo) {
+        pair_range<C, CE>(&sta, &stb, &ta, &tb, lo, hi, lane);
+        single_resume<C, HASN, true>(&sta, &ta, hi, lane);
+        tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane);
+        finish_task<C, CE, HASN, 64, true>(&ta, &da, &p, lane, 0, 0);
+        single_resume<C, HASN, true>(&stb, &tb, hi, lane);
+        tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, pb.nblk, lane);
+        finish_task<C, CE, HASN, 64, true>(&tb, &db, &p, lane, 0, 1);
+    } else {
+        // two tasks that share no usable run of fast blocks: each was filled with directions, walk them as they are
+        // (B's fill came last, so A's side buffers and direction words are complete in memory as well)
+        finish_task<C, CE, HASN, 64, true>(&ta, &da, &p, lane, 0, 0);
+        finish_task<C, CE, HASN, 64, true>(&tb, &db, &p, lane, 0, 1);
+    }
+}
+
+#ifndef GAMDP_PAIR_WAVES_PER_SIMD
+#define GAMDP_PAIR_WAVES_PER_SIMD 4
+#endif
+template <int C, int CE>
+__global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_p(const LaunchParams p)
+{
+    const int lane = threadIdx.x;
+    u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
+    for (;;) {
+        u32 qi = 0;
+        if (lane == 0) qi = atomicAdd(p.cursor, 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (2 * qi >= p.n_tasks) break;   // n_tasks is even (the host pads the last pair)
+        run_pair<C, CE>(p, qi, slot, lane);
     }
 }
 
@@ -300,6 +424,7 @@ int kernel_cols(int kid)
     case K_C17_CE4: case K_C17_CE4_N: case K_GEN_C17: return 17;
     case K_C5_CE0: case K_C5_CE0_N: case K_GEN_C5: return 5;
     case K_Q19_CE15: case K_Q19_CE15_N: return 19;
+    case K_P17_CE4: return 17;
     case K_GEN_C2: return 2;
     case K_GEN_C3: return 3;
     case K_GEN_C9: return 9;
@@ -307,10 +432,15 @@ int kernel_cols(int kid)
     }
 }
 
-int kernel_waves_per_cu(int) { return 4 * GAMDP_WAVES_PER_SIMD; }
-int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : 1; }
+int kernel_waves_per_cu(int kid) { return 4 * (kid == K_P17_CE4 ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
+int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : 1); }
+int kernel_ckpt_words(int kid) { return kid == K_P17_CE4 ? (int)PairFmt<17>::CK_WORDS : kernel_cols(kid) * 64; }
 
-int kernel_bnd_words(int kid) { return kernel_tasks_per_wave(kid) > 1 ? (int)Strip<QL>::BND_WORDS : (int)Strip<64>::BND_WORDS; }
+int kernel_bnd_words(int kid)
+{
+    if (kid == K_P17_CE4) return (int)PairFmt<17>::BND_WORDS;
+    return kernel_tasks_per_wave(kid) > 1 ? (int)Strip<QL>::BND_WORDS : (int)Strip<64>::BND_WORDS;
+}
 
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
 {
@@ -321,6 +451,7 @@ int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
     case K_C17_CE4_N: hipLaunchKernelGGL((k_align<17, 4, true>), g, b, 0, s, p); break;
     case K_C5_CE0:    hipLaunchKernelGGL((k_align<5, 0, false>), g, b, 0, s, p); break;
     case K_C5_CE0_N:  hipLaunchKernelGGL((k_align<5, 0, true>), g, b, 0, s, p); break;
+    case K_P17_CE4:    hipLaunchKernelGGL((k_align_p<17, 4>), g, b, 0, s, p); break;
     case K_Q19_CE15:   hipLaunchKernelGGL((k_align_q<19, 15, false>), g, b, 0, s, p); break;
     case K_Q19_CE15_N: hipLaunchKernelGGL((k_align_q<19, 15, true>), g, b, 0, s, p); break;
     case K_GEN_C2:    hipLaunchKernelGGL((k_align<2, -1, true>), g, b, 0, s, p); break;

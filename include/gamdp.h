@@ -129,7 +129,7 @@ typedef struct gamdp_mb_out {
 /* ---- context ------------------------------------------------------------------------------ */
 int gamdp_ctx_create(int device, gamdp_ctx** out);
 void gamdp_ctx_destroy(gamdp_ctx* ctx);
-/* bound the scratch arena (direction matrix) in bytes; 0 = default (60 % of free HBM) */
+/* bound the scratch arena (direction matrix) in bytes; 0 = default (75 % of free HBM) */
 int gamdp_ctx_set_arena_bytes(gamdp_ctx* ctx, uint64_t bytes);
 const char* gamdp_last_error(const gamdp_ctx* ctx);
 /* the hipStream_t the kernels run on, as an opaque pointer */

@@ -233,6 +233,49 @@ def test_n_aware_kernels_on_every_case_in_a_fresh_process():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_one_task_per_wavefront_band512_kernel_in_a_fresh_process():
+    """Band-512 batches without N run two tasks per wavefront with their fast blocks in packed f16 (kernel_pair.inc) as
+    soon as there are two tasks; GAMDP_NO_PAIR=1 keeps the one-task direction-free kernel, which single-task batches
+    (and odd leftovers) still use: the band-512 cases of this file must be bit-exact on it too."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_NO_PAIR"):
+        pytest.skip("already inside the no-pair child")
+    env = dict(os.environ, GAMDP_NO_PAIR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "direction_free or golden_large or medium_pairs or random_cases_vs_oracle or pairs_of_unequal"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
+def test_pairs_of_unequal_tasks_band512():
+    """Two tasks per wavefront: partners of very different length / window / flags (the packed range is the common run of
+    fast blocks; with none the pair falls back to directions for every cell), an odd task count, 3 to 40 kb."""
+    rng = random.Random(512)
+    cases = []
+    for n, sub, ins, dele in ((40000, 0.03, 0.01, 0.01), (9000, 0.03, 0.01, 0.01), (9100, 0.02, 0.03, 0.001), (3000, 0.03, 0.01, 0.01),
+                              (2500, 0.0, 0.0, 0.0), (700, 0.05, 0.01, 0.01), (22000, 0.02, 0.001, 0.03), (21000, 0.04, 0.012, 0.012),
+                              (15000, 0.03, 0.01, 0.01)):
+        a = _cases.rand_seq(rng, n)
+        b = _cases.mutate(rng, a, sub, ins, dele) or "A"
+        cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    a = _cases.rand_seq(rng, 30000)
+    b = _cases.mutate(rng, a[4000:], 0.02, 0.01, 0.01)
+    for ba, ea, bb, eb, fs, fe in ((4000, len(a) - 1, 0, len(b) - 1, True, False), (3900, len(a) - 1, 0, len(b) - 1, False, True),
+                                   (4000, 18000, 0, len(b) - 1, False, False), (4200, len(a) + 100, 100, 22000, False, False)):
+        cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb, fs=fs, fe=fe))
+    assert len(cases) % 2 == 1
+    n_ok = 0
+    for want_ops in (False, True):
+        res = run_cases(cases, want_ops=want_ops)
+        for k, (cs, r) in enumerate(zip(cases, res)):
+            o, ops = oracle_for(cs, want_ops)
+            assert r.key() == o.key(), (k, len(cs["a"]), r.key(), o.key())
+            if want_ops:
+                assert r.ops == ops, k
+            n_ok += o.status == 0
+    assert n_ok >= 24
+
+
 def band150_stress_cases():
     """Band-150 cases for both kernel shapes (one task / four tasks per wavefront): pairs from 40 bases to 60 kb in one
     batch (so the four tasks of a wavefront differ in length, top / end block ranges and direction-free range), drifting
