@@ -92,7 +92,8 @@ enum KernelId : int {
 
 int kernel_cols(int kid);
 // launches on `stream`; returns hipError_t as int
-int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream);
+int launch_align(int kid, const LaunchParams& p, unsigned n_slots, unsigned dyn_lds, void* stream);
+unsigned kernel_static_lds(int kid);  // static LDS bytes of a variant
 // occupancy hint: resident waves per CU for this variant
 int kernel_waves_per_cu(int kid);
 int kernel_bnd_words(int kid);  // boundary words per block of the direction-free kernels

@@ -75,6 +75,7 @@ struct Prepared {
 struct Ctx {
     int device = -1;
     int n_cu = 0;
+    u32 max_lds_per_wg = 65536;
     hipStream_t stream = nullptr;
     std::string err;
     u64 arena_limit = 0;

@@ -442,26 +442,49 @@ int kernel_bnd_words(int kid)
     return kernel_tasks_per_wave(kid) > 1 ? (int)Strip<QL>::BND_WORDS : (int)Strip<64>::BND_WORDS;
 }
 
-int launch_align(int kid, const LaunchParams& p, unsigned n_slots, void* stream)
+namespace {
+// the kernel behind a variant id, as a host-side function pointer
+const void* kernel_ptr(int kid)
 {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 g(n_slots), b(64);
     switch (kid) {
-    case K_C17_CE4:   hipLaunchKernelGGL((k_align<17, 4, false>), g, b, 0, s, p); break;
-    case K_C17_CE4_N: hipLaunchKernelGGL((k_align<17, 4, true>), g, b, 0, s, p); break;
-    case K_C5_CE0:    hipLaunchKernelGGL((k_align<5, 0, false>), g, b, 0, s, p); break;
-    case K_C5_CE0_N:  hipLaunchKernelGGL((k_align<5, 0, true>), g, b, 0, s, p); break;
-    case K_P17_CE4:    hipLaunchKernelGGL((k_align_p<17, 4>), g, b, 0, s, p); break;
-    case K_Q19_CE15:   hipLaunchKernelGGL((k_align_q<19, 15, false>), g, b, 0, s, p); break;
-    case K_Q19_CE15_N: hipLaunchKernelGGL((k_align_q<19, 15, true>), g, b, 0, s, p); break;
-    case K_GEN_C2:    hipLaunchKernelGGL((k_align<2, -1, true>), g, b, 0, s, p); break;
-    case K_GEN_C3:    hipLaunchKernelGGL((k_align<3, -1, true>), g, b, 0, s, p); break;
-    case K_GEN_C5:    hipLaunchKernelGGL((k_align<5, -1, true>), g, b, 0, s, p); break;
-    case K_GEN_C9:    hipLaunchKernelGGL((k_align<9, -1, true>), g, b, 0, s, p); break;
-    case K_GEN_C17:   hipLaunchKernelGGL((k_align<17, -1, true>), g, b, 0, s, p); break;
-    default: return (int)hipErrorInvalidValue;
+    case K_C17_CE4:    return (const void*)k_align<17, 4, false>;
+    case K_C17_CE4_N:  return (const void*)k_align<17, 4, true>;
+    case K_C5_CE0:     return (const void*)k_align<5, 0, false>;
+    case K_C5_CE0_N:   return (const void*)k_align<5, 0, true>;
+    case K_P17_CE4:    return (const void*)k_align_p<17, 4>;
+    case K_Q19_CE15:   return (const void*)k_align_q<19, 15, false>;
+    case K_Q19_CE15_N: return (const void*)k_align_q<19, 15, true>;
+    case K_GEN_C2:     return (const void*)k_align<2, -1, true>;
+    case K_GEN_C3:     return (const void*)k_align<3, -1, true>;
+    case K_GEN_C5:     return (const void*)k_align<5, -1, true>;
+    case K_GEN_C9:     return (const void*)k_align<9, -1, true>;
+    case K_GEN_C17:    return (const void*)k_align<17, -1, true>;
+    default:           return nullptr;
     }
-    return (int)hipGetLastError();
+}
+}  // namespace
+
+// static LDS bytes of a variant (0 if unknown)
+unsigned kernel_static_lds(int kid)
+{
+    static unsigned cache[K_COUNT] = {0};
+    if (kid < 0 || kid >= K_COUNT) return 0;
+    if (cache[kid] == 0) {
+        hipFuncAttributes a;
+        const void* f = kernel_ptr(kid);
+        if (f && hipFuncGetAttributes(&a, f) == hipSuccess) cache[kid] = (unsigned)a.sharedSizeBytes;
+    }
+    return cache[kid];
+}
+
+// dyn_lds: unused dynamic LDS that only limits how many workgroups share a CU (see the launch planner in gamdp_host.cpp)
+int launch_align(int kid, const LaunchParams& p, unsigned n_slots, unsigned dyn_lds, void* stream)
+{
+    const void* f = kernel_ptr(kid);
+    if (!f) return (int)hipErrorInvalidValue;
+    LaunchParams lp = p;
+    void* args[] = {&lp};
+    return (int)hipLaunchKernel(f, dim3(n_slots), dim3(64), args, dyn_lds, static_cast<hipStream_t>(stream));
 }
 
 }  // namespace gamdp
