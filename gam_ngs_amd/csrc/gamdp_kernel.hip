@@ -173,7 +173,7 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
 }
 
 // block modes of one task (scalar) and its runs: b0 = first fast block, b1 = first block after that fast run
-struct Plan { int nblk, b0, b1; int64_t iE0, iE1; int X, LE, begin_a, w; };
+struct Plan { int nblk, b0, b1, b2; int64_t iE0, iE1; int X, LE, begin_a, w; };  // b2 = first block after the end run that follows
 __device__ __forceinline__ int plan_mode(const Plan& pl, const int blk)
 {
     const int tau0 = blk * ROWS;
@@ -192,7 +192,9 @@ __device__ __forceinline__ Plan make_plan(const Tk& t)
     while (b0 < pl.nblk && plan_mode(pl, b0) != M_FAST) ++b0;
     int b1 = b0;
     while (b1 < pl.nblk && plan_mode(pl, b1) == M_FAST) ++b1;
-    pl.b0 = b0; pl.b1 = b1;
+    int b2 = b1;
+    while (b2 < pl.nblk && plan_mode(pl, b2) == M_END) ++b2;
+    pl.b0 = b0; pl.b1 = b1; pl.b2 = b2;
     return pl;
 }
 
@@ -229,8 +231,9 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);
     // the packed range: fast blocks of BOTH tasks, whole groups of 4 blocks, at least one tagged fast block in front of it
     // for either task (what a lane receives at a group start must be its neighbour's plain last column)
-    int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, hi = min(pa.b1, pb.b1) & ~3;
-    if (!(p.ckpt_off != 0 && hi - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = hi = 0;
+    // ... followed, still packed, by the blocks up to where the first task leaves its fast + end run
+    int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
+    if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
     BlockState<C> sta, stb;
     init_row0<C, HASN, true>(&sta, &ta, lane);
@@ -238,7 +241,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     init_row0<C, HASN, true>(&stb, &tb, lane);
     tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : pb.nblk, lane);
     if (hi > lo) {
-        pair_range<C, CE>(&sta, &stb, &ta, &tb, lo, hi, lane);
+        pair_range<C, CE, false>(&sta, &stb, &ta, &tb, lo, mid, lane);
+        if (hi > mid) pair_range<C, CE, true>(&sta, &stb, &ta, &tb, mid, hi, lane);
         single_resume<C, HASN, true>(&sta, &ta, hi, lane);
         tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane);
         finish_task<C, CE, HASN, 64, true>(&ta, &da, &p, lane, 0, 0);
