@@ -108,7 +108,7 @@ def cpu_baseline(length, band, pair_ids):
     return rec, keys
 
 
-def kernel_name(band, n_tasks=0):
+def kernel_name(band, n_tasks=0, length=50000):
     """The kernel instantiation the library picks for N-free contigs of this band and batch size (gamdp_host.cpp)."""
     from gam_ngs_amd import lib as L
     forced_n = bool(os.environ.get("GAMDP_DIAG_FORCE_N")) and L.load_library().gamdp_build_info() & 1
@@ -118,8 +118,10 @@ def kernel_name(band, n_tasks=0):
             return "k_align_p<17,4>"      # two tasks per wavefront, fast blocks in packed f16
         return "k_align<17,4,%s>" % n
     if band == 150:
-        quad_min = int(os.environ.get("GAMDP_QUAD_MIN", "5120"))
-        return ("k_align_q<19,15,%s>" if n_tasks >= max(1, quad_min) else "k_align<5,0,%s>") % n
+        # >= 32 768 N-free tasks of >= 4 k rows: eight per wavefront, packed f16; >= 5 120 tasks of >= 8 k rows: four
+        if n == "false" and n_tasks >= 32768 and length >= 4096 and not os.environ.get("GAMDP_NO_PAIR"):
+            return "k_align_o<19,15>"
+        return ("k_align_q<19,15,%s>" if (n_tasks >= 5120 and length >= 8192) else "k_align<5,0,%s>") % n
     y = 2 * band + 1
     c = next(c for c in (2, 3, 5, 9, 17) if y <= c * 64)
     return "k_align<%d,-1,true>" % c
@@ -274,7 +276,7 @@ def main():
         avg_launch_s = (m["kernel_ms"] / 1e3) / max(1, launches)
         cells_per_launch = m["cells_rank"] * steps / max(1, launches)
         achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        kname = kernel_name(args.band, m["P"])
+        kname = kernel_name(args.band, m["P"], length)
         traffic_bytes, traffic_src, traffic_commit = measured_traffic(m["P"], length, band, launches == steps, kname)
         line = {
             "metric": "GCUPS", "value": m["gcups"], "unit": "GCUPS", "n_gpus": world, "steps": steps,

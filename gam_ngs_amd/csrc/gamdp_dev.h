@@ -84,6 +84,7 @@ enum KernelId : int {
     K_C5_CE0,        // band 150 (gam-merge's live default), ACGT only
     K_C5_CE0_N,      // band 150, N-aware
     K_P17_CE4,       // band 512, ACGT only, TWO tasks per wavefront, fast blocks in packed f16 (kernel_pair.inc)
+    K_O19_CE15,      // band 150, ACGT only, EIGHT tasks per wavefront: two quads, fast blocks in packed f16
     K_Q19_CE15,      // band 150, ACGT only, FOUR tasks per wavefront (16 lanes x 19 columns each): big batches
     K_Q19_CE15_N,    // the same, N-aware
     K_GEN_C2, K_GEN_C3, K_GEN_C5, K_GEN_C9, K_GEN_C17,  // any band, N-aware, runtime edge column

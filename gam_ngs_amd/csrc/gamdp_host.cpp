@@ -504,22 +504,28 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     {
         static const long quad_min = [] { const char* e = std::getenv("GAMDP_QUAD_MIN"); return e ? std::atol(e) : -1L; }();
         const size_t thr = quad_min >= 0 ? (size_t)quad_min : (size_t)n_cu * (size_t)kernel_waves_per_cu(0);
-        const int from[2] = {K_C5_CE0, K_C5_CE0_N}, to[2] = {K_Q19_CE15, K_Q19_CE15_N};
+        const int from[2] = {K_C5_CE0, K_C5_CE0_N};
+        static const bool no_pair150 = std::getenv("GAMDP_NO_PAIR") != nullptr;
         for (int v = 0; v < 2; v++) {
             auto& g = groups[from[v]];
             if (g.empty() || g.size() < std::max<size_t>(thr, 1)) continue;
-            // ... and long enough: below ~8 k rows the top / end blocks and the four one-after-the-other walks of a
+            // ... and long enough: below ~8 k rows the top / end blocks and the one-after-the-other walks of a
             // wavefront eat what the fill gains (measured: 400 000 x 2 kb pairs 15 % slower, 5 kb equal, 20 kb 8 % faster)
             u64 rows = 0;
             for (u32 i : g) rows += (u64)prep[i].dt.X;
-            if (quad_min < 0 && rows / g.size() < 8192) continue;
-            const u64 C = (u64)kernel_cols(to[v]);
+            // without N and with enough tasks to fill the chip eight at a time: two quads per wavefront, packed f16 (from
+            // ~4 k rows on: 400 000 x 5 kb pairs measured 5 % faster than one task per wavefront, 9 % faster than four)
+            const bool octo = v == 0 && !no_pair150 && !diag_no_dirfree && (quad_min >= 0 || rows / g.size() >= 4096) &&
+                              g.size() >= (quad_min >= 0 ? (size_t)quad_min : 8 * (size_t)n_cu * (size_t)kernel_waves_per_cu(K_O19_CE15));
+            if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
+            const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
+            const u64 C = (u64)kernel_cols(to);
             for (u32 i : g) {
                 const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
-                prep[i].kid = to[v];
+                prep[i].kid = to;
                 prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1) * C * 64;
             }
-            groups[to[v]] = std::move(g);
+            groups[to] = std::move(g);
             g.clear();
         }
     }
@@ -569,6 +575,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; };
     std::vector<Launch> launches;
+    // (Measured and dropped: handing the leftover of a multi-task group -- less than one round -- to a finer-grained kernel
+    // as a launch of its own, and starting every other wavefront half a fill late to take the wavefronts of a launch of
+    // equal tasks out of lock-step.  The first costs more than the stragglers do (launches are sequential), the second
+    // changed nothing beyond noise.)
     for (int kid = 0; kid < K_COUNT; kid++) {
         auto& g = groups[kid];
         if (g.empty()) continue;
@@ -593,7 +603,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // (C*64 words) and, per block, 512 boundary words instead (gamdp_kernel.hip, do_block_df)
             u64 ckpt_words = 0, bnd_words = 0;
             const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
-            const bool pair = kid == K_P17_CE4;               // ... and, for the pairs, its own direction words
+            const bool pair = kid == K_P17_CE4 || kid == K_O19_CE15;   // ... and, for the pairs (of tasks / of quads), its own direction words
             if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
                 const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * (u64)kernel_ckpt_words(kid);

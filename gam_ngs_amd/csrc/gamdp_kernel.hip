@@ -406,6 +406,81 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     }
 }
 
+// ---- eight tasks per wavefront: two quads of band-150 tasks, their common fast + end blocks in packed f16 -------------
+// The band-150 twin of run_pair: quad A's four tasks in the low halves, quad B's in the high halves, one task per DPP row
+// in either.  The int32 phases (top blocks, what is left after the packed range) run one quad after the other with the
+// tagged four-task code; the eight walks run one task at a time.
+template <int C, int CE, bool HASN>
+__device__ __forceinline__ void quad_tagged_blocks(BlockState<C>* st, const Tk* t, const Plan& pl, const int from, const int to, const int lane)
+{
+    for (int blk = from; blk < to;) {
+        const int m = quad_or(plan_mode(pl, blk));
+        if (m == M_FAST) {
+            int e = blk + 1;
+            while (e < to && quad_or(plan_mode(pl, e)) == M_FAST) ++e;
+            fast_range<C, CE, HASN, false, false, QL>(st, t, blk, e, lane);
+            blk = e;
+        } else {
+            if (m == M_TOP) slow_block<C, CE, HASN, M_TOP, QL>(st, t, blk, lane);
+            else if (m == M_END) slow_block<C, CE, HASN, M_END, QL>(st, t, blk, lane);
+            else slow_block<C, CE, HASN, M_BOTH, QL>(st, t, blk, lane);
+            ++blk;
+        }
+    }
+}
+
+template <int C, int CE>
+__device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
+{
+    constexpr bool HASN = false;
+    const int sub = lane >> 4;
+    const DevTask& da = p.tasks[8 * qi + (u32)sub];       // every lane: the tasks of its DPP row
+    const DevTask& db = p.tasks[8 * qi + 4u + (u32)sub];
+    // slot: [dir quad A][dir quad B][side buffers of the 8 tasks][packed rows][packed boundaries]
+    u32* const side = slot + 2 * p.dir_words;
+    Tk ta = make_tk(da, p, slot, side + (u64)sub * 4u * p.ypad, slot);
+    Tk tb = make_tk(db, p, slot + p.dir_words, side + (u64)(4 + sub) * 4u * p.ypad, slot);
+    const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);   // per lane
+    const int nA = quad_max(pa.nblk), nB = quad_max(pb.nblk);
+    int lo = (quad_max(max(pa.b0, pb.b0)) + 1 + 3) & ~3, mid = quad_min(min(pa.b1, pb.b1)) & ~3, hi = quad_min(min(pa.b2, pb.b2)) & ~3;
+    if (!(p.ckpt_off != 0 && mid - lo >= 8) || quad_or((int)((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE))) lo = mid = hi = 0;
+    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    BlockState<C> sta, stb;
+    init_row0<C, HASN, true, QL>(&sta, &ta, lane);
+    quad_tagged_blocks<C, CE, HASN>(&sta, &ta, pa, 0, hi > lo ? lo : nA, lane);
+    init_row0<C, HASN, true, QL>(&stb, &tb, lane);
+    quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : nB, lane);
+    if (hi > lo) {
+        pair_range<C, CE, false, QL>(&sta, &stb, &ta, &tb, lo, mid, lane);
+        if (hi > mid) pair_range<C, CE, true, QL>(&sta, &stb, &ta, &tb, mid, hi, lane);
+        single_resume<C, HASN, true, QL>(&sta, &ta, hi, lane);
+        quad_tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, nA, lane);
+        single_resume<C, HASN, true, QL>(&stb, &tb, hi, lane);
+        quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, nB, lane);
+    }
+    // end cell + walk: one task at a time, the whole wavefront on it
+#pragma unroll 1
+    for (int s8 = 0; s8 < 2 * QT; ++s8) {
+        const int half = s8 >> 2, s4 = s8 & 3;
+        const Tk ts = bcast_tk(half ? tb : ta, QL * s4);
+        finish_task<C, CE, HASN, QL, true>(&ts, &p.tasks[8 * qi + (u32)s8], &p, lane, QL * s4, half);
+    }
+}
+
+template <int C, int CE>
+__global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_o(const LaunchParams p)
+{
+    const int lane = threadIdx.x;
+    u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
+    for (;;) {
+        u32 qi = 0;
+        if (lane == 0) qi = atomicAdd(p.cursor, 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (8 * qi >= p.n_tasks) break;   // n_tasks is a multiple of 8 (the host pads the last wavefront)
+        run_octo<C, CE>(p, qi, slot, lane);
+    }
+}
+
 template <int C, int CE, bool HASN>
 __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align_q(const LaunchParams p)
 {
@@ -429,6 +504,7 @@ int kernel_cols(int kid)
     case K_C5_CE0: case K_C5_CE0_N: case K_GEN_C5: return 5;
     case K_Q19_CE15: case K_Q19_CE15_N: return 19;
     case K_P17_CE4: return 17;
+    case K_O19_CE15: return 19;
     case K_GEN_C2: return 2;
     case K_GEN_C3: return 3;
     case K_GEN_C9: return 9;
@@ -436,13 +512,14 @@ int kernel_cols(int kid)
     }
 }
 
-int kernel_waves_per_cu(int kid) { return 4 * (kid == K_P17_CE4 ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
-int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : 1); }
-int kernel_ckpt_words(int kid) { return kid == K_P17_CE4 ? (int)PairFmt<17>::CK_WORDS : kernel_cols(kid) * 64; }
+int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19_CE15) ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
+int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
+int kernel_ckpt_words(int kid) { return kid == K_P17_CE4 ? (int)PairFmt<17, 64>::CK_WORDS : (kid == K_O19_CE15 ? (int)PairFmt<19, QL>::CK_WORDS : kernel_cols(kid) * 64); }
 
 int kernel_bnd_words(int kid)
 {
-    if (kid == K_P17_CE4) return (int)PairFmt<17>::BND_WORDS;
+    if (kid == K_P17_CE4) return (int)PairFmt<17, 64>::BND_WORDS;
+    if (kid == K_O19_CE15) return (int)PairFmt<19, QL>::BND_WORDS;
     return kernel_tasks_per_wave(kid) > 1 ? (int)Strip<QL>::BND_WORDS : (int)Strip<64>::BND_WORDS;
 }
 
@@ -456,6 +533,7 @@ const void* kernel_ptr(int kid)
     case K_C5_CE0:     return (const void*)k_align<5, 0, false>;
     case K_C5_CE0_N:   return (const void*)k_align<5, 0, true>;
     case K_P17_CE4:    return (const void*)k_align_p<17, 4>;
+    case K_O19_CE15:   return (const void*)k_align_o<19, 15>;
     case K_Q19_CE15:   return (const void*)k_align_q<19, 15, false>;
     case K_Q19_CE15_N: return (const void*)k_align_q<19, 15, true>;
     case K_GEN_C2:     return (const void*)k_align<2, -1, true>;

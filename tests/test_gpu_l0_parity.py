@@ -318,15 +318,16 @@ def test_band150_stress_cases():
 
 
 def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
-    """GAMDP_QUAD_MIN=1 sends every band-150 call of a batch through the throughput kernels (four tasks per wavefront,
-    16 lanes x 19 columns, direction-free fill) instead of only batches larger than the chip's wave slots: the band-150
-    cases of this file must come out bit-exact; a second child adds GAMDP_DIAG_FORCE_N (diagnostics build) for their
-    N-aware twin and a third switches the direction-free fill off."""
+    """GAMDP_QUAD_MIN=1 sends every band-150 call of a batch through the throughput kernels instead of only batches larger
+    than the chip's wave slots: eight tasks per wavefront (two quads, fast blocks in packed f16) for contigs without N,
+    four tasks per wavefront (16 lanes x 19 columns, direction-free int32 fill) for the rest.  The band-150 cases of this
+    file must come out bit-exact; further children keep the four-task int32 kernel on N-free input (GAMDP_NO_PAIR), force
+    its N-aware twin (GAMDP_DIAG_FORCE_N, diagnostics build) and switch the direction-free fill off."""
     import os, subprocess, sys
     if os.environ.get("GAMDP_QUAD_MIN"):
         pytest.skip("already inside the four-task child")
     sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap"
-    for extra in ({}, dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
+    for extra in ({}, dict(GAMDP_NO_PAIR="1"), dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
         env = dict(os.environ, GAMDP_QUAD_MIN="1", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", sel],
                            env=env, capture_output=True, text=True, timeout=1500)
