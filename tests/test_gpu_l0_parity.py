@@ -247,6 +247,19 @@ def test_one_task_per_wavefront_band512_kernel_in_a_fresh_process():
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
 
 
+def test_pieces_over_two_contexts_in_a_fresh_process():
+    """Batches of >= 262 144 calls go through in four pieces on two host threads / contexts (host work of one piece hidden
+    behind the other's kernel); GAMDP_CHUNK_MIN=16 applies that to the small batches of this file: same results."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_CHUNK_MIN"):
+        pytest.skip("already inside the chunked child")
+    env = dict(os.environ, GAMDP_CHUNK_MIN="16")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "random_cases_vs_oracle or medium_pairs or golden_small_cases_summary or begin_a_at or band150_stress"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
 def test_pairs_of_unequal_tasks_band512():
     """Two tasks per wavefront: partners of very different length / window / flags (the packed range is the common run of
     fast blocks; with none the pair falls back to directions for every cell), an odd task count, 3 to 40 kb."""
