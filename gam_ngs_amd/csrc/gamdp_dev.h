@@ -92,6 +92,7 @@ enum KernelId : int {
 };
 
 int kernel_cols(int kid);
+int kernel_dir_block_words(int kid);  // words per block (16 row-times) of a task's direction image
 // launches on `stream`; returns hipError_t as int
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, unsigned dyn_lds, void* stream);
 unsigned kernel_static_lds(int kid);  // static LDS bytes of a variant

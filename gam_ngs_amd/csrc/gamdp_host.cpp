@@ -409,7 +409,7 @@ static int prepare_task(const ITask& it, Prepared& pr)
     const int C = kernel_cols(pr.kid);
     const int LE = (int)((Y - 1) / (u64)C);
     const u64 nblk = (X - 1 + (u64)LE) / 16 + 1;
-    pr.dir_words = nblk * (u64)C * 64;
+    pr.dir_words = nblk * (u64)kernel_dir_block_words(pr.kid);
     DevTask& d = pr.dt;
     const DevSeq& da = it.a_rc ? it.sa->rc[it.a_id] : it.sa->fwd[it.a_id];
     const DevSeq& db = it.b_rc ? it.sb->rc[it.b_id] : it.sb->fwd[it.b_id];
@@ -523,7 +523,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             for (u32 i : g) {
                 const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
                 prep[i].kid = to;
-                prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1) * C * 64;
+                prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1) * (u64)kernel_dir_block_words(to);
             }
             groups[to] = std::move(g);
             g.clear();
@@ -605,7 +605,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
             const bool pair = kid == K_P17_CE4 || kid == K_O19_CE15;   // ... and, for the pairs (of tasks / of quads), its own direction words
             if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
-                const u64 cw = (u64)kernel_cols(kid) * 64, nblk = dirw / cw + 1;
+                const u64 cw = (u64)kernel_dir_block_words(kid), nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * (u64)kernel_ckpt_words(kid);
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);
             }

@@ -472,6 +472,16 @@ __global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_o(const
 {
     const int lane = threadIdx.x;
     u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
+#ifdef GAMDP_STAGGER_US
+    {   // experiment: the odd wave slots of every SIMD start late, so that fill and walk phases of co-resident waves overlap
+        u32 hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < 100ll * GAMDP_STAGGER_US) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
     for (;;) {
         u32 qi = 0;
         if (lane == 0) qi = atomicAdd(p.cursor, 1u);
@@ -514,7 +524,21 @@ int kernel_cols(int kid)
 
 int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19_CE15) ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
-int kernel_ckpt_words(int kid) { return kid == K_P17_CE4 ? (int)PairFmt<17, 64>::CK_WORDS : (kid == K_O19_CE15 ? (int)PairFmt<19, QL>::CK_WORDS : kernel_cols(kid) * 64); }
+// words per block of the direction image: lane major (LANE_WORDS per lane) in the direction-free kernels
+int kernel_dir_block_words(int kid)
+{
+    switch (kid) {
+    case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: return IMG_WORDS<17, true>;
+    case K_Q19_CE15: case K_Q19_CE15_N: case K_O19_CE15: return IMG_WORDS<19, true>;
+    default: return kernel_cols(kid) * 64;
+    }
+}
+int kernel_ckpt_words(int kid)
+{
+    if (kid == K_P17_CE4) return (int)PairFmt<17, 64>::CK_WORDS;
+    if (kid == K_O19_CE15) return (int)PairFmt<19, QL>::CK_WORDS;
+    return kernel_dir_block_words(kid);
+}
 
 int kernel_bnd_words(int kid)
 {

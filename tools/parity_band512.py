@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Focused parity run for the direction-free band-512 kernels: random windowed cases of 0.6-14 kb (so that the
-direction-free range is empty, one group, a few groups ...), with and without N, with and without edit strings, and
-once more with a tiny scratch arena (few resident slots, several launches)."""
+"""Focused parity run for the direction-free / packed kernels of one band (default 512; `parity_band512.py 9 150` with
+GAMDP_QUAD_MIN=1 for the four- and eight-task band-150 kernels): random windowed cases of 0.6-14 kb (so that the
+direction-free range is empty, one group, a few groups ...; partners of a wavefront of very different length), with and
+without N, with and without edit strings, and once more with a tiny scratch arena (few resident slots, several launches)."""
 import os
 import random
 import sys
@@ -17,6 +18,7 @@ from _gpu import oracle_for, run_cases  # noqa: E402
 
 def main():
     n_total = 0
+    band = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         rng = random.Random(5120 + seed)
         cases = []
@@ -30,7 +32,7 @@ def main():
             ea = rng.choice([n - 1, n - 1, rng.randint(ba, n + 600)])
             bb = rng.choice([0, 0, rng.randint(0, min(300, len(b) - 1))])
             eb = rng.choice([len(b) - 1, len(b) - 1, rng.randint(bb, len(b) + 50)])
-            cases.append(dict(a=a.encode(), b=b.encode(), band=512, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb,
+            cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb,
                               fs=rng.random() < 0.2, fe=rng.random() < 0.2))
         if seed % 3 == 2:
             _gpu.ctx().set_arena_bytes(40 << 20)   # a handful of slots
@@ -44,7 +46,7 @@ def main():
                 if r.key() != o.key() or (want_ops and r.ops != ops):
                     print("MISMATCH seed", seed, {k: v for k, v in cs.items() if k not in ("a", "b")}, len(cs["a"]), len(cs["b"]), r.key(), o.key())
                     sys.exit(1)
-    print("band-512 parity passed:", n_total, "comparisons")
+    print("band-%d parity passed:" % band, n_total, "comparisons")
 
 
 if __name__ == "__main__":
