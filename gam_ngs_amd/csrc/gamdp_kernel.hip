@@ -44,6 +44,9 @@ namespace gamdp {
 namespace {
 
 #include "kernel_common.inc"
+#ifdef GAMDP_EXP_PHASES
+__shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise() calls of walk_many
+#endif
 #include "kernel_fill.inc"
 #include "kernel_pair.inc"
 #include "kernel_strip.inc"
@@ -319,6 +322,52 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
     return t;
 }
 
+#include "kernel_walk.inc"
+
+// end cell, walk and result of the NT tasks of a wavefront: the end cells one task at a time (the whole wavefront scans),
+// the interior of all walks side by side (walk_many), then per task the steps the reference treats specially + the result
+template <int C, int CE, bool HASN, bool PK, int NT>
+__device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 first_task, const Tk& ta, const Tk& tb, const int lane)
+{
+    WalkCarry wcs[NT];
+    int skip = 0;
+#ifdef GAMDP_EXP_PHASES
+    const long long tp0 = wall_clock64();
+#endif
+#pragma unroll 1
+    for (int s = 0; s < NT; ++s) {
+        const Tk ts = bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
+        end_cell<C>(&ts, lane, &wcs[s]);
+        const u32 fl = (u32)uni((int)p.tasks[first_task + (u32)s].flags);
+        if (fl & TF_WANT_OPS) skip |= 1 << s;                                                   // the edit string takes one step at a time
+        if (fl & TF_LIVE_MASK & (TF_DIAG_SKIP_TRACEBACK | TF_DIAG_COUNT_MAT)) skip |= (1 << NT) - 1;  // diagnostics: the one-task walk only
+    }
+#ifdef GAMDP_EXP_PHASES
+    const long long tp1 = wall_clock64();
+#endif
+    // (with four int32 tasks the side-by-side walk spends as many vector instructions per task as the one-task walk, which
+    // keeps its bookkeeping on the scalar unit: measured 6 % slower on 98 304 x 50 kb; eight packed tasks: 4 % faster)
+    if constexpr (NT == 8)
+        if (skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT>(&ta, &tb, wcs, skip, lane);
+#ifdef GAMDP_EXP_PHASES
+    const long long tp2 = wall_clock64();
+    int ncalls = 0;
+    for (int s = 0; s < NT; ++s) ncalls += wcs[s].mat_calls;
+#endif
+#pragma unroll 1
+    for (int s = 0; s < NT; ++s) {
+        const Tk ts = bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
+        finish_walk<C, CE, HASN, QL, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, QL * (s & 3), s >> 2, &wcs[s]);
+    }
+#ifdef GAMDP_EXP_PHASES
+    {   // timing experiment: the first task's record carries the phase times of the wavefront (10 ns ticks)
+        const long long tp3 = wall_clock64();
+        DevResult* r = &p.results[p.tasks[first_task].res_idx];
+        if (lane == 0) { r->begin_b = (int)(tp1 - tp0); r->score = (int)(tp2 - tp1); r->n_match = (u32)ncalls; r->length = (u32)(tp3 - tp2); r->first_a = g_exp_mat_ticks; }
+    }
+#endif
+}
+
 template <int C, int CE, bool HASN>
 __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
 {
@@ -398,12 +447,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
             ++blk;
         }
     }
-    // end cell + walk: one task at a time, the whole wavefront on it
-#pragma unroll 1
-    for (int s4 = 0; s4 < QT; ++s4) {
-        const Tk ts = bcast_tk(t, QL * s4);
-        finish_task<C, CE, HASN, LPT>(&ts, &p.tasks[4 * qi + (u32)s4], &p, lane, QL * s4);
-    }
+    finish_many<C, CE, HASN, false, QT>(p, 4 * qi, t, t, lane);
 }
 
 // ---- eight tasks per wavefront: two quads of band-150 tasks, their common fast + end blocks in packed f16 -------------
@@ -440,6 +484,10 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     u32* const side = slot + 2 * p.dir_words;
     Tk ta = make_tk(da, p, slot, side + (u64)sub * 4u * p.ypad, slot);
     Tk tb = make_tk(db, p, slot + p.dir_words, side + (u64)(4 + sub) * 4u * p.ypad, slot);
+#ifdef GAMDP_EXP_PHASES
+    const long long tf0 = wall_clock64();
+    g_exp_mat_ticks = 0;
+#endif
     const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);   // per lane
     const int nA = quad_max(pa.nblk), nB = quad_max(pb.nblk);
     int lo = (quad_max(max(pa.b0, pb.b0)) + 1 + 3) & ~3, mid = quad_min(min(pa.b1, pb.b1)) & ~3, hi = quad_min(min(pa.b2, pb.b2)) & ~3;
@@ -458,13 +506,13 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
         single_resume<C, HASN, true, QL>(&stb, &tb, hi, lane);
         quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, nB, lane);
     }
-    // end cell + walk: one task at a time, the whole wavefront on it
-#pragma unroll 1
-    for (int s8 = 0; s8 < 2 * QT; ++s8) {
-        const int half = s8 >> 2, s4 = s8 & 3;
-        const Tk ts = bcast_tk(half ? tb : ta, QL * s4);
-        finish_task<C, CE, HASN, QL, true>(&ts, &p.tasks[8 * qi + (u32)s8], &p, lane, QL * s4, half);
-    }
+#ifdef GAMDP_EXP_PHASES
+    const long long tf1 = wall_clock64();
+#endif
+    finish_many<C, CE, HASN, true, 2 * QT>(p, 8 * qi, ta, tb, lane);
+#ifdef GAMDP_EXP_PHASES
+    if (lane == 0) p.results[p.tasks[8 * qi].res_idx].begin_a = (int)(tf1 - tf0);
+#endif
 }
 
 template <int C, int CE>
