@@ -293,11 +293,14 @@ class BandedSmithWaterman:
             t.begin_a, t.end_a, t.begin_b, t.end_b = begin_a & m64, end_a & m64, begin_b & m64, end_b & m64
         out = (L.Result * n)()
         ops_struct = None
+        # want_ops: one flag for the batch, or one per call (a capacity of 0 = no edit string for that call)
+        per_call = list(want_ops) if isinstance(want_ops, (list, tuple)) else [bool(want_ops)] * n
+        want_ops = any(per_call)
         if want_ops:
             caps = []
             for i, cl in enumerate(calls):
                 band = tasks[i].band
-                caps.append(cl[0].size() + cl[3].size() + 2 * band + 64)
+                caps.append(cl[0].size() + cl[3].size() + 2 * band + 64 if per_call[i] else 0)
             offs = [0] * n
             tot = 0
             for i in range(n):
@@ -320,7 +323,7 @@ class BandedSmithWaterman:
         res = []
         for i in range(n):
             ops = None
-            if want_ops:
+            if want_ops and per_call[i]:
                 ops = ""
                 if out[i].status == L.ST_OK:
                     raw = buf.raw[offs[i]:offs[i] + out[i].length]
