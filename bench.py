@@ -24,7 +24,9 @@ The printed JSON line also carries
   verified_pairs  how many of those CPU results were compared field for field with the GPU results of the same
                   pairs (outside the timed region); any difference fails the run;
   l1              the merge-block driver (gamdp_align_merge_blocks, band 150) on a GAGE-shaped synthetic
-                  two-assembly workload: merge blocks/s, GCUPS, share of the call spent in GPU kernels, rounds.
+                  two-assembly workload: merge blocks/s, GCUPS, share of the call spent in GPU kernels, rounds;
+  band150         the headline's own pairs once more at band 150, gam-merge's live band (N = 1, default workload only):
+                  GCUPS, kernel, roofline fraction, and a sample verified against the CPU path like the headline's.
 """
 import argparse
 import ctypes as C
@@ -149,6 +151,50 @@ def measured_traffic(P_launch, length, band, launches_ok, kernel):
     return tj["hbm_bytes_per_launch"], "profiles/" + name, tj.get("commit")
 
 
+def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
+    """The pairs of the headline run (still resident) aligned at band 150, gam-merge's only live band
+    (banded_smith_waterman.hpp:38): the "band150" object of the line.  `verify` pairs are compared with the CPU path."""
+    from gam_ngs_amd import lib as L
+    sset, tasks, out = m["_keep"]
+    P, band = m["P"], 150
+    for k in range(P):
+        tasks[k].band = band
+
+    def step():
+        rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
+        if rc != 0:
+            raise SystemExit("gamdp_align_batch (band 150) failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+
+    for _ in range(warmup):
+        step()
+    ctx.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    kernel_ms, launches = ctx.kernel_time()
+    cells = sum(out[k].cells for k in range(P))
+    bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
+    if bad:
+        raise SystemExit("bench.py: %d pairs came back without an alignment at band 150" % bad)
+    per_launch_s = kernel_ms / 1e3 / max(1, launches)
+    rec = {"workload": "the same %d pairs at band 150" % P, "gcups": cells / dt / 1e9, "steps": steps, "ms_per_step": dt * 1e3,
+           "kernel": kernel_name(band, P, length), "kernel_ms_per_launch": per_launch_s * 1e3, "launches": int(launches),
+           "roofline_frac": (cells * steps / max(1, launches)) * B_ALG / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s > 0 else 0.0}
+    if verify:
+        n = min(verify, P)
+        ids = [m["first"] + k * m["stride"] for k in range(n)]
+        cpu, cpu_keys = cpu_baseline(length, band, ids)
+        diff = [k for k in range(n) if tuple(out[k].key()) != tuple(cpu_keys[k])]
+        if diff:
+            raise SystemExit("bench.py: band 150: GPU result of pair %d differs from the CPU %s: %r vs %r"
+                             % (ids[diff[0]], cpu["kind"], out[diff[0]].key(), cpu_keys[diff[0]]))
+        rec["verified_pairs"] = n
+    for k in range(P):
+        tasks[k].band = 512
+    return rec
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (this parent has
     not touched the GPU and never will) and leave with its exit code."""
@@ -177,6 +223,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = 32 per core)")
     ap.add_argument("--no-l1", action="store_true", help="skip the merge-block (L1, band 150) record")
     ap.add_argument("--l1-genome", type=int, default=2_900_000, help="genome size of the L1 workload (S. aureus: 2.9 Mb)")
+    ap.add_argument("--no-band150", action="store_true", help="skip the band-150 record of the same pairs")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -318,6 +365,8 @@ def main():
                 raise SystemExit("bench.py: GPU result of pair %d differs from the CPU %s: %r vs %r (%d of %d differ)"
                                  % (ids[k], rec["kind"], gpu_keys[k], cpu_keys[k], len(diff), n_cpu))
             line["verified_pairs"] = n_cpu   # status, begin, score, #matches, length, first/last match, identity
+        if not args.no_band150 and world == 1 and band == 512 and "_keep" in m:
+            line["band150"] = band150_record(ctx, m, length, verify=0 if args.no_cpu_baseline else 128)
         if not args.no_l1 and world == 1:
             import bench_l1
             line["l1"] = bench_l1.run(ctx, genome=args.l1_genome)

@@ -2,7 +2,7 @@
 # packed f16; default for >= 32 768 N-free tasks) against four (GAMDP_NO_PAIR=1); full / fill only / fill + strips
 mkdir -p gpurun_out/ab150
 D=$PWD/gam_ngs_amd/libgamdp_diag.so
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --band 150"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --band 150"
 for mode in octo quad; do
  unset GAMDP_NO_PAIR
  if [ $mode = quad ]; then export GAMDP_NO_PAIR=1; fi

@@ -2,7 +2,7 @@
 # against one task per wavefront (GAMDP_NO_PAIR=1); full / fill only / fill + strips.  libgamdp_diag_w5.so = the pair
 # kernel compiled for 5 waves per SIMD (hand-built for this comparison; the host side still plans 4 per SIMD).
 mkdir -p gpurun_out/ab512
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --pairs ${PAIRS:-40960}"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --pairs ${PAIRS:-40960}"
 for mode in pair pair_w5 nopair; do
   D=$PWD/gam_ngs_amd/libgamdp_diag.so
   unset GAMDP_NO_PAIR

@@ -7,7 +7,7 @@ for lib in "$@"; do
   unset GAMDP_DIAG_SKIP_TRACEBACK GAMDP_DIAG_COUNT_MAT
   if [ $mode != full ]; then export GAMDP_DIAG_SKIP_TRACEBACK=1; fi
   if [ $mode = fillmat ]; then export GAMDP_DIAG_COUNT_MAT=1; fi
-  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 $ARGS > gpurun_out/abfm/${tag}_$mode.log 2>&1
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 $ARGS > gpurun_out/abfm/${tag}_$mode.log 2>&1
   python - gpurun_out/abfm/${tag}_$mode.log ${tag}_$mode <<'PY'
 import json,sys
 for l in open(sys.argv[1]):

@@ -3,7 +3,7 @@ ARGS="$1"; shift
 mkdir -p gpurun_out/ablibs
 for lib in "$@"; do
  if [ "$lib" = "-" ]; then unset GAMDP_LIB; tag=prod; else export GAMDP_LIB=$PWD/$lib; tag=$(basename $lib .so); fi
- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 $ARGS > gpurun_out/ablibs/$tag.log 2>&1
+ python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 $ARGS > gpurun_out/ablibs/$tag.log 2>&1
  python - gpurun_out/ablibs/$tag.log $tag <<'PY'
 import json,sys
 for l in open(sys.argv[1]):

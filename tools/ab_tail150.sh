@@ -1,7 +1,7 @@
 # Band 150, eight tasks per wavefront: how much of the kernel is the tail of the last round?  100 000 tasks are 3.05 rounds
 # of 8 x 4 096; 98 304 are exactly 3.  Optional $1 = another build of the library to compare (e.g. 2-lane strips).
 mkdir -p gpurun_out/tail150
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --band 150 --len 50000"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --band 150 --len 50000"
 for lib in "" "$1"; do
  tag=prod; if [ -n "$lib" ]; then tag=alt; export GAMDP_LIB=$PWD/$lib; fi
  for P in 32768 65536 98304 100000 114688 131072; do

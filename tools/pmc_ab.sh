@@ -10,7 +10,7 @@ for lib in "$@"; do
             "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_READ_sum" \
             "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmcab/${tag}_$i -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-l1 $ARGS > gpurun_out/pmcab/${tag}_$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmcab/${tag}_$i -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-l1 --no-band150 $ARGS > gpurun_out/pmcab/${tag}_$i.log 2>&1
  done
 done
 python3 - <<'PY'

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r02_sweep
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150"
 run() { name=$1; shift; $B "$@" > gpurun_out/r02_sweep/$name.log 2>&1; python - gpurun_out/r02_sweep/$name.log $name <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
