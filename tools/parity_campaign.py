@@ -19,11 +19,12 @@ def main():
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--per-seed", type=int, default=1000)
     ap.add_argument("--long", type=int, default=0, help="additional 3-9 kb related pairs (bands 64..512, N, windows, force flags)")
+    ap.add_argument("--first-seed", type=int, default=0, help="continue a campaign: seeds first .. first + seeds - 1 (and another set of long pairs)")
     args = ap.parse_args()
     band_sets = [(0, 1, 2, 5, 8, 20, 150), (3, 31, 32, 63, 64, 95, 96), (127, 128, 150, 159, 160, 161, 287, 288, 289),
                  (512, 300, 543, 511, 513), (150,), (512,), (7, 40, 70, 100, 200, 256, 400)]
     total = ok = 0
-    for seed in range(args.seeds):
+    for seed in range(args.first_seed, args.first_seed + args.seeds):
         rng = random.Random(77000 + seed)
         bands = band_sets[seed % len(band_sets)]
         max_len = rng.choice([120, 400, 400, 1200, 3000])
@@ -42,7 +43,7 @@ def main():
         print("seed %d bands %s max_len %d ok (%d checked so far, %d with alignments)" % (seed, bands, max_len, total, ok), flush=True)
     if args.long:
         from concurrent.futures import ThreadPoolExecutor
-        rng = random.Random(4242)
+        rng = random.Random(4242 + args.first_seed)
         cases = []
         for i in range(args.long):
             n = rng.randint(3000, 9000)
