@@ -508,3 +508,43 @@ def write_blocks(path: str, blocks):
             setattr(r, k, v.encode("latin1") if isinstance(v, str) else v)
     if lib.gamdp_blocks_write(str(path).encode(), arr, len(blocks)):
         raise L.GamdpError("cannot write " + str(path))
+
+
+def _block_array(blocks):
+    arr = (L.BlockRec * max(1, len(blocks)))()
+    for r, b in zip(arr, blocks):
+        for k in L.BlockRec.KEYS:
+            v = b[k]
+            setattr(r, k, v.encode("latin1") if isinstance(v, str) else v)
+    return arr
+
+
+def no_blocks_contigs(blocks, n_master: int, n_slave: int):
+    """getNoBlocksContigs (Block.cc:810-862): (master flags, slave flags), 1 = no block lies on the contig."""
+    lib = L.load_library()
+    m, s = (C.c_uint8 * max(1, n_master))(), (C.c_uint8 * max(1, n_slave))()
+    rc = lib.gamdp_no_blocks_contigs(_block_array(blocks), len(blocks), n_master, n_slave, m, s)
+    if rc:
+        raise L.GamdpError("a block names a contig outside the assemblies (the reference exits here)")
+    return list(m[:n_master]), list(s[:n_slave])
+
+
+def no_blocks_after_filter(filtered, n_master: int, n_slave: int, master_nbc, slave_nbc):
+    """getNoBlocksAfterFilterContigs (Block.cc:865-925): contigs that lost all their blocks in the coverage filter."""
+    lib = L.load_library()
+    m, s = (C.c_uint8 * max(1, n_master))(), (C.c_uint8 * max(1, n_slave))()
+    mb, sb = (C.c_uint8 * max(1, n_master))(*master_nbc), (C.c_uint8 * max(1, n_slave))(*slave_nbc)
+    rc = lib.gamdp_no_blocks_after_filter(_block_array(filtered), len(filtered), n_master, n_slave, mb, sb, m, s)
+    if rc:
+        raise L.GamdpError("a block names a contig outside the assemblies (the reference exits here)")
+    return list(m[:n_master]), list(s[:n_slave])
+
+
+def write_selected_fasta(assembly, select, path):
+    """The contigs with select[i] != 0 as gam-merge writes .noblocks.BF/.AF.fasta and .notmerged.fasta
+    (src/Merge.cc:336-373, 414-431): `stream << contig << std::endl`."""
+    lib = L.load_library()
+    sel = (C.c_uint8 * max(1, len(select)))(*[int(bool(x)) for x in select])
+    if lib.gamdp_fasta_write_selected(assembly.handle, sel, str(path).encode()):
+        raise L.GamdpError("cannot write " + str(path))
+

@@ -526,3 +526,76 @@ int gamdp_pctgs_write_descriptors(const gamdp_pctgs* set, const char* path)
 }
 
 }  // extern "C"
+
+// ---- gam-merge's side outputs (src/Merge.cc:273-297, 335-373, 412-431) ------------------------------------------
+namespace {
+// Block.cc:810-862 / 865-925 up to the final flip: which contigs carry a block
+int mark_block_contigs(const gamdp_block_rec* blocks, uint64_t n, uint32_t n_master, uint32_t n_slave, uint8_t* m, uint8_t* s)
+{
+    if ((n && !blocks) || !m || !s) return GAMDP_EINVAL;
+    std::memset(m, 0, n_master);
+    std::memset(s, 0, n_slave);
+    for (uint64_t k = 0; k < n; k++) {
+        const int32_t mi = blocks[k].m_ctg, si = blocks[k].s_ctg;
+        if (mi < 0 || (uint32_t)mi >= n_master || si < 0 || (uint32_t)si >= n_slave) return GAMDP_EINVAL;  // the reference exits here
+        m[mi] = 1;
+        s[si] = 1;
+    }
+    return 0;
+}
+}  // namespace
+
+int gamdp_no_blocks_contigs(const gamdp_block_rec* blocks, uint64_t n_blocks, uint32_t n_master, uint32_t n_slave,
+                            uint8_t* master_nbc, uint8_t* slave_nbc)
+{
+    const int rc = mark_block_contigs(blocks, n_blocks, n_master, n_slave, master_nbc, slave_nbc);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n_master; i++) master_nbc[i] ^= 1;   // flip: contigs WITHOUT blocks
+    for (uint32_t i = 0; i < n_slave; i++) slave_nbc[i] ^= 1;
+    return 0;
+}
+
+int gamdp_no_blocks_after_filter(const gamdp_block_rec* filtered, uint64_t n_blocks, uint32_t n_master, uint32_t n_slave,
+                                 const uint8_t* master_nbc, const uint8_t* slave_nbc, uint8_t* master_af, uint8_t* slave_af)
+{
+    if (!master_nbc || !slave_nbc) return GAMDP_EINVAL;
+    const int rc = mark_block_contigs(filtered, n_blocks, n_master, n_slave, master_af, slave_af);
+    if (rc) return rc;
+    // |= the contigs that had no block before the filter, then flip (Block.cc:915-923)
+    for (uint32_t i = 0; i < n_master; i++) master_af[i] = !(master_af[i] || master_nbc[i]);
+    for (uint32_t i = 0; i < n_slave; i++) slave_af[i] = !(slave_af[i] || slave_nbc[i]);
+    return 0;
+}
+
+int gamdp_pctgs_not_merged(const gamdp_pctgs* set, const uint8_t* slave_nbc_bf, const uint8_t* slave_nbc_af, uint8_t* not_merged)
+{
+    const PctgSet* p = reinterpret_cast<const PctgSet*>(set);
+    if (!p || !slave_nbc_bf || !slave_nbc_af || !not_merged) return GAMDP_EINVAL;
+    const size_t n = p->slave->codes.size();
+    std::memset(not_merged, 0, n);   // first: used = in a paired contig | no blocks before | no blocks after (Merge.cc:416-426)
+    for (const Pctg& pc : p->pctgs) for (int32_t id : pc.slave_ids) not_merged[id] = 1;
+    for (size_t i = 0; i < n; i++) not_merged[i] = !(not_merged[i] || slave_nbc_bf[i] || slave_nbc_af[i]);
+    return 0;
+}
+
+int gamdp_fasta_write_selected(const gamdp_fasta* fa, const uint8_t* select, const char* path)
+{
+    const Fasta* f = reinterpret_cast<const Fasta*>(fa);
+    if (!f || !select || !path) return GAMDP_EINVAL;
+    FILE* out = std::fopen(path, "w");
+    if (!out) return GAMDP_EINVAL;
+    std::string rec;
+    for (size_t i = 0; i < f->codes.size(); i++) {
+        if (!select[i]) continue;
+        const std::vector<uint8_t>& c = f->codes[i];
+        rec = ">" + f->names[i];
+        for (size_t k = 0; k < c.size(); k++) {
+            if (k % 60 == 0) rec.push_back('\n');
+            rec.push_back(LETTER[c[k] > 4 ? 4 : c[k]]);
+        }
+        rec.push_back('\n');
+        if (std::fwrite(rec.data(), 1, rec.size(), out) != rec.size()) { std::fclose(out); return GAMDP_EINVAL; }
+    }
+    return std::fclose(out) ? GAMDP_EINVAL : 0;
+}
+

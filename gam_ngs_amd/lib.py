@@ -21,6 +21,7 @@ SYMBOLS = [
     "gamdp_multi_seqset_create", "gamdp_multi_seqset_create_from_fasta", "gamdp_multi_seqset_destroy",
     "gamdp_multi_seqset_on", "gamdp_multi_align_batch", "gamdp_multi_align_merge_blocks", "gamdp_partition_lpt",
     "gamdp_blocks_open", "gamdp_blocks_close", "gamdp_blocks_count", "gamdp_blocks_data", "gamdp_blocks_write",
+    "gamdp_no_blocks_contigs", "gamdp_no_blocks_after_filter", "gamdp_pctgs_not_merged", "gamdp_fasta_write_selected",
 ]
 
 EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
@@ -222,5 +223,9 @@ def load_library():
     lib.gamdp_blocks_data.argtypes = [vp]
     lib.gamdp_blocks_data.restype = C.POINTER(BlockRec)
     lib.gamdp_blocks_write.argtypes = [C.c_char_p, C.POINTER(BlockRec), u64]
+    lib.gamdp_no_blocks_contigs.argtypes = [C.POINTER(BlockRec), u64, u32, u32, vp, vp]
+    lib.gamdp_no_blocks_after_filter.argtypes = [C.POINTER(BlockRec), u64, u32, u32, vp, vp, vp, vp]
+    lib.gamdp_pctgs_not_merged.argtypes = [vp, vp, vp, vp]
+    lib.gamdp_fasta_write_selected.argtypes = [vp, vp, C.c_char_p]
     _lib = lib
     return lib

@@ -135,6 +135,15 @@ class PairedContigs:
         self.lib.gamdp_pctgs_contig_use(self.handle, m, s)
         return list(m[:len(self.master)]), list(s[:len(self.slave)])
 
+    def not_merged(self, slave_nbc_bf, slave_nbc_af):
+        """Merge.cc:416-429: slave contigs in no paired contig and in neither no-blocks set (-> .notmerged.fasta)."""
+        n = len(self.slave)
+        a, b = (C.c_uint8 * max(1, n))(*slave_nbc_bf), (C.c_uint8 * max(1, n))(*slave_nbc_af)
+        out = (C.c_uint8 * max(1, n))()
+        if self.lib.gamdp_pctgs_not_merged(self.handle, a, b, out):
+            raise L.GamdpError("gamdp_pctgs_not_merged failed")
+        return list(out[:n])
+
     def write_fasta(self, path):
         if self.lib.gamdp_pctgs_write_fasta(self.handle, str(path).encode()):
             raise L.GamdpError("cannot write " + str(path))

@@ -330,6 +330,22 @@ int gamdp_pctgs_write_fasta(const gamdp_pctgs* p, const char* path);
 /* ".pctgs" (PairedContig.cc:305-349) */
 int gamdp_pctgs_write_descriptors(const gamdp_pctgs* p, const char* path);
 
+/* ---- gam-merge's side outputs: slave contigs no block lies on, slave contigs no paired contig uses -------------
+ * (src/Merge.cc:273-277, 294-297, 335-373, 412-431; host only).  All flag arrays are one byte per contig. */
+/* getNoBlocksContigs (Block.cc:810-862): master_nbc[i] / slave_nbc[i] = 1 iff no block lies on contig i.  A block with a
+ * contig id outside [0, n_master) / [0, n_slave) is where the reference prints an error and exits: GAMDP_EINVAL. */
+int gamdp_no_blocks_contigs(const gamdp_block_rec* blocks, uint64_t n_blocks, uint32_t n_master, uint32_t n_slave,
+                            uint8_t* master_nbc, uint8_t* slave_nbc);
+/* getNoBlocksAfterFilterContigs (Block.cc:865-925): contigs that had blocks before the coverage filter
+ * (master_nbc / slave_nbc = the arrays of the call above on the unfiltered list) and have none in `filtered`. */
+int gamdp_no_blocks_after_filter(const gamdp_block_rec* filtered, uint64_t n_blocks, uint32_t n_master, uint32_t n_slave,
+                                 const uint8_t* master_nbc, const uint8_t* slave_nbc, uint8_t* master_af, uint8_t* slave_af);
+/* Merge.cc:416-429: not_merged[i] = 1 iff slave contig i is in no paired contig and in neither no-blocks set */
+int gamdp_pctgs_not_merged(const gamdp_pctgs* p, const uint8_t* slave_nbc_bf, const uint8_t* slave_nbc_af, uint8_t* not_merged);
+/* the contigs with select[i] != 0, each as `os << contig << std::endl` (io_contig.code.hpp:246-262: ">" name, 60 bases
+ * per line): ".noblocks.BF.fasta", ".noblocks.AF.fasta", ".notmerged.fasta" (Merge.cc:336-373, 414-431) */
+int gamdp_fasta_write_selected(const gamdp_fasta* f, const uint8_t* select, const char* path);
+
 /* Synthetic pair k of the benchmark workload (BASELINE.json config 5): master = len uniform ACGT
  * codes, slave = master with 3 % substitutions, 1 % insertions, 1 % deletions (splitmix64 keyed by
  * k).  slave must hold len + len/8 + 64 codes; returns the slave length. */

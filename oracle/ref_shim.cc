@@ -254,4 +254,22 @@ int64_t gamref_render_pctgs(const char* const* m_names, const char* const* m_seq
     return (int64_t)f.size();
 }
 
+// The contigs with select[i] != 0 as gam-merge writes its ".noblocks.*.fasta" / ".notmerged.fasta" side outputs:
+// `stream << *contig << std::endl` with the reference's own operator<<(ostream&, const Contig&) (src/Merge.cc:350, 370, 429).
+int64_t gamref_render_contigs(const char* const* names, const char* const* seqs, uint32_t n, const uint8_t* select,
+                              char* out, uint64_t cap)
+{
+    std::ostringstream os;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!select[i]) continue;
+        Contig ctg(make_contig(seqs[i], std::strlen(seqs[i])));
+        ctg.set_name(names[i]);
+        os << ctg << std::endl;
+    }
+    const std::string t = os.str();
+    if (t.size() + 1 > cap) return -1;
+    std::memcpy(out, t.c_str(), t.size() + 1);
+    return (int64_t)t.size();
+}
+
 }  // extern "C"

@@ -126,3 +126,35 @@ def test_files_to_gam_fasta_several_graphs_in_graphs_list_order(tmp_path):
                            "--devices", "0,0"], check=True, timeout=600)
     assert open(tmp_path / "run2.gam.fasta").read() == fasta and open(tmp_path / "run2.pctgs").read() == desc
     assert open(tmp_path / "out2.tsv").read() == open(tmp_path / "out.tsv").read()
+    # the side outputs of src/Merge.cc:335-373, 412-431: slave contigs without blocks before / after the coverage filter,
+    # slave contigs nothing used -- from the .blocks file gam-merge loaded and the one its filter kept
+    from gam_ngs_amd import api
+
+    def rec(m, sid, b):
+        return dict(n_reads=int(b[6]), m_block_reads_len=100, m_reads_len=100, s_block_reads_len=100, s_reads_len=100, m_ctg=m,
+                    m_begin=int(b[0]), m_end=int(b[1]), s_ctg=sid, s_begin=int(b[2]), s_end=int(b[3]), m_strand=b[4], s_strand=b[5])
+    kept = [rec(mb["m_id"], mb["s_id"], b) for g in pb["graphs"] for l in g for mb in l for b in mb["blocks"]]
+    in_kept = set(r["s_ctg"] for r in kept)
+    lost = [i for i in range(len(slave)) if i not in in_kept][::2]     # these had blocks the coverage filter removed
+    api.write_blocks(tmp_path / "all.blocks", kept + [rec(0, i, (0, 99, 0, 99, "+", "+", 3)) for i in lost])
+    api.write_blocks(tmp_path / "kept.blocks", kept)
+    subprocess.run(args + [str(tmp_path / "mb.tsv"), str(tmp_path / "out3.tsv"), "--pctgs", str(tmp_path / "run3"), "--vote", "master",
+                           "--blocks", str(tmp_path / "all.blocks"), "--blocks-filtered", str(tmp_path / "kept.blocks")], check=True, timeout=600)
+    used = set()
+    for p in want:
+        used |= set(p.slave_ids)
+    s_bf = [i for i in range(len(slave)) if i not in in_kept and i not in lost]
+    unused = [i for i in range(len(slave)) if i not in used and i not in s_bf and i not in lost]
+    assert s_bf and lost and unused
+
+    def text(ids):
+        out = []
+        for i in ids:
+            seq = G.to_ascii(pb["slave"][i]["seq"]).decode()
+            out.append(">s%d\n" % i + "".join(seq[k:k + 60] + "\n" for k in range(0, len(seq), 60)))
+        return "".join(out)
+    assert open(tmp_path / "run3.noblocks.BF.fasta").read() == text(s_bf)
+    assert open(tmp_path / "run3.noblocks.AF.fasta").read() == text(lost)
+    assert open(tmp_path / "run3.notmerged.fasta").read() == text(unused)
+    assert open(tmp_path / "run3.gam.fasta").read() == fasta
+

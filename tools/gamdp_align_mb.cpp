@@ -2,7 +2,7 @@
 // lib/src/pctg/BuildPctgFunctions.cc:82-84) on an MI355X from files, without the rest of gam-merge.
 //
 //   gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D | --devices D0,D1,..]
-//                  [--repeat K] [--pctgs PREFIX] [--vote master|slave|fail]
+//                  [--repeat K] [--pctgs PREFIX] [--vote master|slave|fail] [--blocks all.blocks [--blocks-filtered kept.blocks]]
 //
 // --devices runs the step on several GPUs of the node (gamdp_multi_*: merge blocks partitioned statically by predicted
 // cells, one host thread + context per device, no collective); a device may be listed twice.  The output is the same
@@ -19,6 +19,10 @@
 // holding a merge block on which the reference would have thrown contributes nothing, like ThreadedBuildPctg.cc:322-329.
 // --vote says what to do when a block region needs the BAM evidence of computeZScore (PctgBuilder.cc:147-168), which
 // this tool does not have: take the master's copy, the slave's, or stop (default).
+// With --blocks (the .blocks file gam-merge loaded; --blocks-filtered = what its coverage filter kept, default: all of it)
+// the side outputs of src/Merge.cc:335-373, 412-431 are written too: PREFIX.noblocks.BF.fasta, PREFIX.noblocks.AF.fasta
+// (slave contigs no block lies on, before / after the filter) and PREFIX.notmerged.fasta (slave contigs in neither set and
+// in no paired contig).  Contig ids in the .blocks files are positions in the two FASTA files.
 //
 // It only uses the C ABI of include/gamdp.h (this file is also the C++ usage example of the library).
 #include <chrono>
@@ -45,11 +49,11 @@ static int region_vote(void*, int32_t, int32_t, int32_t, int32_t, int32_t, int32
 int main(int argc, char** argv)
 {
     if (argc < 5) die("usage: gamdp-align-mb <master.fasta> <slave.fasta> <mergeblocks.tsv> <out.tsv> [--band N] [--device D] [--repeat K] "
-                      "[--pctgs PREFIX] [--vote master|slave|fail]");
+                      "[--pctgs PREFIX] [--vote master|slave|fail] [--blocks all.blocks [--blocks-filtered kept.blocks]]");
     unsigned band = GAMDP_DEFAULT_BAND;
     int device = 0, repeat = 1;
     std::vector<int> devices;
-    std::string pctg_prefix;
+    std::string pctg_prefix, blocks_path, filtered_path;
     for (int i = 5; i + 1 < argc; i += 2) {
         if (!std::strcmp(argv[i], "--band")) band = (unsigned)std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(argv[i + 1]);
@@ -61,6 +65,8 @@ int main(int argc, char** argv)
         }
         else if (!std::strcmp(argv[i], "--repeat")) repeat = std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--pctgs")) pctg_prefix = argv[i + 1];
+        else if (!std::strcmp(argv[i], "--blocks")) blocks_path = argv[i + 1];
+        else if (!std::strcmp(argv[i], "--blocks-filtered")) filtered_path = argv[i + 1];
         else if (!std::strcmp(argv[i], "--vote")) {
             if (!std::strcmp(argv[i + 1], "master")) g_vote = 0;
             else if (!std::strcmp(argv[i + 1], "slave")) g_vote = 1;
@@ -189,6 +195,25 @@ int main(int argc, char** argv)
             die("cannot write " + pctg_prefix + ".gam.fasta / .pctgs");
         std::fprintf(stderr, "gamdp-align-mb: %u paired contigs (%u merged, %zu graphs dropped) -> %s.gam.fasta, %s.pctgs\n", gamdp_pctgs_count(pc),
                      gamdp_pctgs_merged_count(pc), dropped, pctg_prefix.c_str(), pctg_prefix.c_str());
+        if (!blocks_path.empty()) {   // src/Merge.cc:273-297, 335-373, 412-431
+            gamdp_blocks *all = nullptr, *kept = nullptr;
+            if (gamdp_blocks_open(blocks_path.c_str(), 1, &all)) die("cannot read " + blocks_path);
+            if (!filtered_path.empty() && gamdp_blocks_open(filtered_path.c_str(), 1, &kept)) die("cannot read " + filtered_path);
+            const uint32_t nm = gamdp_fasta_count(fm), ns = gamdp_fasta_count(fs);
+            std::vector<uint8_t> m_bf(nm + 1), s_bf(ns + 1), m_af(nm + 1), s_af(ns + 1), unused(ns + 1);
+            if (gamdp_no_blocks_contigs(gamdp_blocks_data(all), gamdp_blocks_count(all), nm, ns, m_bf.data(), s_bf.data()))
+                die(blocks_path + ": a block names a contig the FASTA files do not have (master and slave swapped?)");
+            const gamdp_blocks* k = kept ? kept : all;
+            if (gamdp_no_blocks_after_filter(gamdp_blocks_data(k), gamdp_blocks_count(k), nm, ns, m_bf.data(), s_bf.data(), m_af.data(), s_af.data()))
+                die("the filtered .blocks file names a contig the FASTA files do not have");
+            if (gamdp_pctgs_not_merged(pc, s_bf.data(), s_af.data(), unused.data())) die("gamdp_pctgs_not_merged failed");
+            if (gamdp_fasta_write_selected(fs, s_bf.data(), (pctg_prefix + ".noblocks.BF.fasta").c_str()) ||
+                gamdp_fasta_write_selected(fs, s_af.data(), (pctg_prefix + ".noblocks.AF.fasta").c_str()) ||
+                gamdp_fasta_write_selected(fs, unused.data(), (pctg_prefix + ".notmerged.fasta").c_str()))
+                die("cannot write the side outputs of " + pctg_prefix);
+            gamdp_blocks_close(all);
+            gamdp_blocks_close(kept);
+        }
         gamdp_pctgs_destroy(pc);
     }
     gamdp_seqset_destroy(master);
