@@ -121,7 +121,7 @@ def kernel_name(band, n_tasks=0, length=50000):
         return "k_align<17,4,%s>" % n
     if band == 150:
         # >= 32 768 N-free tasks of >= 4 k rows: eight per wavefront, packed f16; >= 5 120 tasks of >= 8 k rows: four
-        if n == "false" and n_tasks >= 32768 and length >= 4096 and not os.environ.get("GAMDP_NO_PAIR"):
+        if n == "false" and ((n_tasks >= 32768 and length >= 4096) or (n_tasks >= 6144 and length >= 8192)) and not os.environ.get("GAMDP_NO_PAIR"):
             return "k_align_o<19,15>"
         return ("k_align_q<19,15,%s>" if (n_tasks >= 5120 and length >= 8192) else "k_align<5,0,%s>") % n
     y = 2 * band + 1
