@@ -573,6 +573,9 @@ int kernel_cols(int kid)
 int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19_CE15) ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
 // words per block of the direction image: lane major (LANE_WORDS per lane) in the direction-free kernels
+static_assert(DIRFREE_OK<4, 17, false> && DIRFREE_OK<4, 17, true> && DIRFREE_OK<15, 19, false> && DIRFREE_OK<15, 19, true> &&
+                  !DIRFREE_OK<0, 5, false> && !DIRFREE_OK<0, 5, true> && !DIRFREE_OK<-1, 17, true> && !DIRFREE_OK<-1, 9, true>,
+              "kernel_dir_block_words() below lists the direction-free kernels by id: keep it in step with DIRFREE_OK");
 int kernel_dir_block_words(int kid)
 {
     switch (kid) {
