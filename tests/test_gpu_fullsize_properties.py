@@ -89,3 +89,34 @@ def test_band150_equals_band512_and_oracle_spot_checks(workload):
         m, s = pairs[k]
         o, _ = O.oracle_align(m, s, 512, 0, LEN - 1, 0, len(s) - 1, want_ops=False)
         assert r512[k].key() == o.key()
+
+
+def test_throughput_kernels_agree_with_each_other_and_the_oracle_at_batch_size():
+    """A batch large enough for the throughput kernels of both bands -- 8 192 library-generated 50 kb pairs: band 512
+    goes through the packed two-task kernel, band 150 (>= 6 144 long N-free calls) through the packed eight-task kernel with
+    its 2-lane strips and side-by-side walks -- must give the same alignment for every pair (these pairs drift far less
+    than 150 columns), and both must equal the CPU oracle on a sample."""
+    from gam_ngs_amd import lib as L
+    c = ctx()
+    P = 8192
+    sset = gam.SequenceSet.synthetic(c, 5000, P, LEN)
+    tasks = (L.Task * P)()
+    for k in range(P):
+        t = tasks[k]
+        t.a_id, t.b_id = 2 * k, 2 * k + 1
+        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, LEN - 1, 0, sset.lengths[2 * k + 1] - 1
+    keys = {}
+    for band in (512, 150):
+        for k in range(P):
+            tasks[k].band = band
+        out = (L.Result * P)()
+        assert c.lib.gamdp_align_batch(c.handle, sset.handle, sset.handle, tasks, P, out, None) == 0
+        keys[band] = [out[k].key() for k in range(P)]
+        assert all(k[0] == L.ST_OK for k in keys[band])
+    assert keys[512] == keys[150]
+    for k in (0, 4095, 4096, 8191, 1234, 6001):
+        m, s = api.synth_pair(5000 + k, LEN)
+        o, _ = O.oracle_align(m, s, 150, 0, LEN - 1, 0, len(s) - 1, want_ops=False)
+        assert tuple(keys[150][k]) == tuple(o.key()), k
+    sset.close()
+
