@@ -497,6 +497,23 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         groups[prep[i].kid].push_back((u32)i);
     }
 
+    // Small band-150 batches (merge-block rounds): one launch instead of two.  The launches of a batch run one after the
+    // other on the context's stream and each lasts as long as its longest task, so a round in which some contigs hold N
+    // paid for two sweeps; the N-aware kernel aligns N-free contigs too (same results, ~4 % more time per cell, which a
+    // latency-bound round does not notice).  Only while everything is resident at once; GAMDP_NO_MERGE_N=1 keeps the split
+    // (A/B measurements); not when GAMDP_QUAD_MIN forces the throughput kernels (tests).
+    {
+        static const bool keep_split = std::getenv("GAMDP_NO_MERGE_N") != nullptr || std::getenv("GAMDP_QUAD_MIN") != nullptr;
+        auto &f = groups[K_C5_CE0], &a = groups[K_C5_CE0_N];
+        if (!keep_split && !f.empty() && !a.empty() && f.size() + a.size() <= (size_t)n_cu * (size_t)kernel_waves_per_cu(K_C5_CE0_N)) {
+            for (u32 i : f) prep[i].kid = K_C5_CE0_N;
+            std::vector<u32> all(f.size() + a.size());
+            std::merge(f.begin(), f.end(), a.begin(), a.end(), all.begin());   // both ascending: stays ascending
+            a.swap(all);
+            f.clear();
+        }
+    }
+
     // Band 150 has two shapes: one task per wavefront (5 columns per lane: the lowest latency per task) and four tasks
     // per wavefront (19 columns per lane, direction-free fill: ~1.7x the throughput).  A batch with more band-150 tasks
     // than the chip has wave slots is throughput-bound and takes the second; merge-block rounds of a few hundred or
