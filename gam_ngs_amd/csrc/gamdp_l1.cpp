@@ -402,11 +402,17 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         for (u32 k = 0; k < in[i].n_blocks && in[i].blocks; k++)
             weight[i] += (u64)frame_len(in[i].blocks[k].s_begin, in[i].blocks[k].s_end) * (2ull * band + 1);
     }
-    // Cohorts: up to 4 host threads, each with its own context (stream, staging buffers, scratch arena) on this device,
-    // at least 48 merge blocks each; the merge blocks are dealt by predicted cells (LPT), so the cohorts' chains have
-    // similar depth.  Results do not depend on the split: every machine only sees its own results.
-    static const int max_cohorts = [] { const char* e = std::getenv("GAMDP_L1_COHORTS"); const int v = e ? std::atoi(e) : 4; return std::min(8, std::max(1, v)); }();
-    const int K = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_cohorts, n / 48));
+    // Cohorts: host threads, each with its own context (stream, staging buffers, scratch arena) on this device; the merge
+    // blocks are dealt by predicted cells (LPT), so the cohorts' chains have similar depth.  A round lasts as long as its
+    // longest call, so smaller cohorts mean shorter rounds that overlap on the (nearly empty) GPU -- up to a point: 4 cohorts
+    // of >= 48 merge blocks, 8 from ~1 500 merge blocks on (measured on the GAGE-shaped workloads: 192 merge blocks 12.5 /
+    // 11.5 / 8.8 / 13.1 ms with 1 / 2 / 4 / 8 cohorts, 1 967 merge blocks 103 / 77 / 60 / 54 / 63 ms with 1 / 2 / 4 / 8 / 12).
+    // GAMDP_L1_COHORTS=k (<= 16) and GAMDP_L1_COHORT_MIN=m set the cap and the floor by hand.  Results do not depend on the
+    // split: every machine only sees its own results.
+    static const int forced_cohorts = [] { const char* e = std::getenv("GAMDP_L1_COHORTS"); return e ? std::min(16, std::max(1, std::atoi(e))) : 0; }();
+    static const size_t cohort_min = [] { const char* e = std::getenv("GAMDP_L1_COHORT_MIN"); const long v = e ? std::atol(e) : 48; return (size_t)std::max(1L, v); }();
+    const int K = forced_cohorts ? (int)std::max<size_t>(1, std::min<size_t>((size_t)forced_cohorts, n / cohort_min))
+                                 : (int)std::max<size_t>(1, std::max(std::min<size_t>(4, n / cohort_min), std::min<size_t>(8, n / (4 * cohort_min))));
     while ((int)c->helpers.size() < K - 1) {
         Ctx* h = new (std::nothrow) Ctx();
         if (!h || h->init(c->device) != 0) { c->set_error("helper context: " + (h ? h->err : std::string("out of memory"))); delete h; return GAMDP_ENODEV; }
