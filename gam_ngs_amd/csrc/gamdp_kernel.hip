@@ -520,16 +520,6 @@ __global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_o(const
 {
     const int lane = threadIdx.x;
     u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
-#ifdef GAMDP_STAGGER_US
-    {   // experiment: the odd wave slots of every SIMD start late, so that fill and walk phases of co-resident waves overlap
-        u32 hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (hwid & 1u) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < 100ll * GAMDP_STAGGER_US) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#endif
     for (;;) {
         u32 qi = 0;
         if (lane == 0) qi = atomicAdd(p.cursor, 1u);
