@@ -74,7 +74,11 @@ struct LaunchParams {
     u32 ypad;              // side-buffer stride in words (>= 2*band+2)
     u64 ckpt_off;          // word offsets inside a slot of the direction-free fill's row / boundary stores
     u64 bnd_off;           // (0 = this launch keeps directions everywhere)
+    u32 flags;             // LP_*
 };
+// the two-task kernel walks its two tasks side by side (kernel_walk.inc) instead of one after the other: set by the host for
+// launches of at most two rounds, where the wavefronts of a SIMD walk at the same time and the scalar unit is the bottleneck
+constexpr u32 LP_WALK_SIDE_BY_SIDE = 1;
 
 // Kernel variants.  C = band columns per lane; CE = (2*band) % C is the in-lane position of the
 // last band column (compile-time for the tuned variants, -1 = runtime for the generic ones).

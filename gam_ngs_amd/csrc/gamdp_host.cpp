@@ -701,6 +701,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.results = d_results; p.ops_buf = d_ops;
             p.scratch = d_scratch; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
             p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
+            static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::atol(e) : 2ull; }();
+            p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
             HIPCHK(this, hipEventRecord(events[li].first, stream));
             const int e = launch_align(L.kid, p, L.n_slots, L.dyn_lds, stream);
             if (e != 0) { set_error(std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)e)); return GAMDP_EHIP; }

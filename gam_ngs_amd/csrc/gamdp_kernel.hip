@@ -221,62 +221,6 @@ __device__ __forceinline__ void tagged_blocks(BlockState<C>* st, const Tk* t, co
     }
 }
 
-template <int C, int CE>
-__device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
-{
-    constexpr bool HASN = false;
-    const DevTask& da = p.tasks[2 * qi];
-    const DevTask& db = p.tasks[2 * qi + 1];
-    // slot: [dir A][dir B][side buffers A][side buffers B][packed rows][packed boundaries]
-    u32* const sideA = slot + 2 * p.dir_words;
-    Tk ta = make_tk(da, p, slot, sideA, slot);
-    Tk tb = make_tk(db, p, slot + p.dir_words, sideA + 4u * p.ypad, slot);
-    const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);
-    // the packed range: fast blocks of BOTH tasks, whole groups of 4 blocks, at least one tagged fast block in front of it
-    // for either task (what a lane receives at a group start must be its neighbour's plain last column)
-    // ... followed, still packed, by the blocks up to where the first task leaves its fast + end run
-    int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
-    if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
-    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
-    BlockState<C> sta, stb;
-    init_row0<C, HASN, true>(&sta, &ta, lane);
-    tagged_blocks<C, CE, HASN>(&sta, &ta, pa, 0, hi > lo ? lo : pa.nblk, lane);
-    init_row0<C, HASN, true>(&stb, &tb, lane);
-    tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : pb.nblk, lane);
-    if (hi > lo) {
-        pair_range<C, CE, false>(&sta, &stb, &ta, &tb, lo, mid, lane);
-        if (hi > mid) pair_range<C, CE, true>(&sta, &stb, &ta, &tb, mid, hi, lane);
-        single_resume<C, HASN, true>(&sta, &ta, hi, lane);
-        tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane);
-        finish_task<C, CE, HASN, 64, true>(&ta, &da, &p, lane, 0, 0);
-        single_resume<C, HASN, true>(&stb, &tb, hi, lane);
-        tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, pb.nblk, lane);
-        finish_task<C, CE, HASN, 64, true>(&tb, &db, &p, lane, 0, 1);
-    } else {
-        // two tasks that share no usable run of fast blocks: each was filled with directions, walk them as they are
-        // (B's fill came last, so A's side buffers and direction words are complete in memory as well)
-        finish_task<C, CE, HASN, 64, true>(&ta, &da, &p, lane, 0, 0);
-        finish_task<C, CE, HASN, 64, true>(&tb, &db, &p, lane, 0, 1);
-    }
-}
-
-#ifndef GAMDP_PAIR_WAVES_PER_SIMD
-#define GAMDP_PAIR_WAVES_PER_SIMD 4
-#endif
-template <int C, int CE>
-__global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_p(const LaunchParams p)
-{
-    const int lane = threadIdx.x;
-    u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
-    for (;;) {
-        u32 qi = 0;
-        if (lane == 0) qi = atomicAdd(p.cursor, 1u);
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        if (2 * qi >= p.n_tasks) break;   // n_tasks is even (the host pads the last pair)
-        run_pair<C, CE>(p, qi, slot, lane);
-    }
-}
-
 // ---- four tasks per wavefront (throughput kernels of gam-merge's live band, 150) ---------------------------------
 // Band 150 is 301 columns: with one task per wavefront a lane owns 5 of them and the per-row work (operand reads, the
 // two hand-offs, the direction bookkeeping of the tagged cell) outweighs the cells.  Here a task takes one DPP row of 16
@@ -326,9 +270,14 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
 
 // end cell, walk and result of the NT tasks of a wavefront: the end cells one task at a time (the whole wavefront scans),
 // the interior of all walks side by side (walk_many), then per task the steps the reference treats specially + the result
-template <int C, int CE, bool HASN, bool PK, int NT>
-__device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 first_task, const Tk& ta, const Tk& tb, const int lane)
+// (LPT = 64: the pair of the two-task kernel, whose Tk values are wave-uniform already; side_by_side = whether to use walk_many)
+template <int C, int CE, bool HASN, bool PK, int NT, int LPT = QL>
+__device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 first_task, const Tk& ta, const Tk& tb, const int lane, const bool side_by_side = true)
 {
+    auto task_tk = [&](const int s) -> Tk {
+        if constexpr (LPT == 64) return s ? tb : ta;
+        else return bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
+    };
     WalkCarry wcs[NT];
     int skip = 0;
 #ifdef GAMDP_EXP_PHASES
@@ -336,7 +285,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
 #endif
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
-        const Tk ts = bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
+        const Tk ts = task_tk(s);
         end_cell<C>(&ts, lane, &wcs[s]);
         const u32 fl = (u32)uni((int)p.tasks[first_task + (u32)s].flags);
         if (fl & TF_WANT_OPS) skip |= 1 << s;                                                   // the edit string takes one step at a time
@@ -347,8 +296,8 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
 #endif
     // (with four int32 tasks the side-by-side walk spends as many vector instructions per task as the one-task walk, which
     // keeps its bookkeeping on the scalar unit: measured 6 % slower on 98 304 x 50 kb; eight packed tasks: 4 % faster)
-    if constexpr (NT == 8)
-        if (skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT>(&ta, &tb, wcs, skip, lane);
+    if constexpr (NT == 8 || LPT == 64)
+        if (side_by_side && skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane);
 #ifdef GAMDP_EXP_PHASES
     const long long tp2 = wall_clock64();
     int ncalls = 0;
@@ -356,8 +305,8 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
 #endif
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
-        const Tk ts = bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
-        finish_walk<C, CE, HASN, QL, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, QL * (s & 3), s >> 2, &wcs[s]);
+        const Tk ts = task_tk(s);
+        finish_walk<C, CE, HASN, LPT, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, (LPT == 64) ? 0 : QL * (s & 3), (LPT == 64) ? s : s >> 2, &wcs[s]);
     }
 #ifdef GAMDP_EXP_PHASES
     {   // timing experiment: the first task's record carries the phase times of the wavefront (10 ns ticks)
@@ -366,6 +315,59 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
         if (lane == 0) { r->begin_b = (int)(tp1 - tp0); r->score = (int)(tp2 - tp1); r->n_match = (u32)ncalls; r->length = (u32)(tp3 - tp2); r->first_a = g_exp_mat_ticks; }
     }
 #endif
+}
+
+template <int C, int CE>
+__device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
+{
+    constexpr bool HASN = false;
+    const DevTask& da = p.tasks[2 * qi];
+    const DevTask& db = p.tasks[2 * qi + 1];
+    // slot: [dir A][dir B][side buffers A][side buffers B][packed rows][packed boundaries]
+    u32* const sideA = slot + 2 * p.dir_words;
+    Tk ta = make_tk(da, p, slot, sideA, slot);
+    Tk tb = make_tk(db, p, slot + p.dir_words, sideA + 4u * p.ypad, slot);
+    const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);
+    // the packed range: fast blocks of BOTH tasks, whole groups of 4 blocks, at least one tagged fast block in front of it
+    // for either task (what a lane receives at a group start must be its neighbour's plain last column)
+    // ... followed, still packed, by the blocks up to where the first task leaves its fast + end run
+    int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
+    if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
+    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    BlockState<C> sta, stb;
+    init_row0<C, HASN, true>(&sta, &ta, lane);
+    tagged_blocks<C, CE, HASN>(&sta, &ta, pa, 0, hi > lo ? lo : pa.nblk, lane);
+    init_row0<C, HASN, true>(&stb, &tb, lane);
+    tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : pb.nblk, lane);
+    if (hi > lo) {
+        pair_range<C, CE, false>(&sta, &stb, &ta, &tb, lo, mid, lane);
+        if (hi > mid) pair_range<C, CE, true>(&sta, &stb, &ta, &tb, mid, hi, lane);
+        single_resume<C, HASN, true>(&sta, &ta, hi, lane);
+        tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane);
+        single_resume<C, HASN, true>(&stb, &tb, hi, lane);
+        tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, pb.nblk, lane);
+    }
+    // (two tasks that share no usable run of fast blocks were each filled with directions: they are walked as they are)
+    // end cells, walks, results: one task after the other in long launches, where the scalar walk of one wavefront hides
+    // behind the fills of its SIMD's other wavefronts; side by side in launches of at most two rounds (LP_WALK_SIDE_BY_SIDE)
+    finish_many<C, CE, HASN, true, 2, 64>(p, 2 * qi, ta, tb, lane, (p.flags & LP_WALK_SIDE_BY_SIDE) != 0);
+}
+
+#ifndef GAMDP_PAIR_WAVES_PER_SIMD
+#define GAMDP_PAIR_WAVES_PER_SIMD 4
+#endif
+template <int C, int CE>
+__global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_p(const LaunchParams p)
+{
+    const int lane = threadIdx.x;
+    u32* slot = p.scratch + (u64)blockIdx.x * p.slot_words;
+    for (;;) {
+        u32 qi = 0;
+        if (lane == 0) qi = atomicAdd(p.cursor, 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (2 * qi >= p.n_tasks) break;   // n_tasks is even (the host pads the last pair)
+        run_pair<C, CE>(p, qi, slot, lane);
+    }
 }
 
 template <int C, int CE, bool HASN>
