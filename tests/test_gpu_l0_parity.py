@@ -247,6 +247,19 @@ def test_one_task_per_wavefront_band512_kernel_in_a_fresh_process():
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
 
 
+def test_two_task_kernel_with_one_after_the_other_walks_in_a_fresh_process():
+    """Short band-512 launches (every batch of this file) walk the two tasks of a wavefront side by side; launches of more
+    than two rounds keep the one-task walk.  GAMDP_SIDE_WALK_ROUNDS=0 applies that choice to the batches of this file."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_SIDE_WALK_ROUNDS"):
+        pytest.skip("already inside the child")
+    env = dict(os.environ, GAMDP_SIDE_WALK_ROUNDS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "direction_free or golden_large or medium_pairs or random_cases_vs_oracle or pairs_of_unequal"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
 def test_pieces_over_two_contexts_in_a_fresh_process():
     """Batches of >= 262 144 calls go through in four pieces on two host threads / contexts (host work of one piece hidden
     behind the other's kernel); GAMDP_CHUNK_MIN=16 applies that to the small batches of this file: same results."""
