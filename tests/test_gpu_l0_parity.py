@@ -118,6 +118,12 @@ def test_medium_pairs_all_kernel_variants():
             assert r.key() == o.key(), (cs["band"], len(cs["a"]), r.key(), o.key())
             if want_ops:
                 assert r.ops == ops
+    # edit strings for every other call only: in the two-task kernel one task of a wavefront then walks step by step while
+    # its partner takes the side-by-side path alone
+    flags = [k % 2 == 0 for k in range(len(cases))]
+    for cs, r, f in zip(cases, run_cases(cases, flags), flags):
+        o, ops = oracle_for(cs, True)
+        assert r.key() == o.key() and r.ops == (ops if f else None), (cs["band"], len(cs["a"]))
 
 
 def test_golden_large_synthetic_pairs():
