@@ -166,10 +166,12 @@ int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint64_t stride_pairs, 
     const u64 total = stride * n;
     std::vector<u32> h2(total / 16 + 4, 0), hn(total / 32 + 4, 0);
     const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> th;
+    Threads pool;
     std::atomic<u32> cursor(0);
+    std::atomic<int> failed(0);
     for (unsigned t = 0; t < nt; t++) {
-        th.emplace_back([&]() {
+        pool.start([&]() {
+            failed |= guarded_thread_body([&]() -> int {
             std::vector<uint8_t> m(len), s(len + len / 8 + 64);
             for (;;) {
                 const u32 k = cursor.fetch_add(1);
@@ -181,9 +183,12 @@ int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint64_t stride_pairs, 
                 pack_into(m.data(), len, false, h2.data(), hn.data(), stride * (2 * k) + SEQ_PAD_BASES);
                 pack_into(s.data(), sl, false, h2.data(), hn.data(), stride * (2 * k + 1) + SEQ_PAD_BASES);
             }
+            return 0;
+            });
         });
     }
-    for (auto& t : th) t.join();
+    pool.join();
+    if (failed) return GAMDP_ENOMEM;
     HIPCHK(ctx, hipMalloc(&d2, h2.size() * sizeof(u32)));
     HIPCHK(ctx, hipMalloc(&dn, hn.size() * sizeof(u32)));
     HIPCHK(ctx, hipMemcpyAsync(d2, h2.data(), h2.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
@@ -270,6 +275,25 @@ Ctx::~Ctx()
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+u64 Ctx::arena_budget()
+{
+    if (arena_limit == 0) {
+        size_t fr = 0, tot = 0;
+        if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+        arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.75);
+    }
+    return arena_limit;
+}
+
+void Ctx::trim_scratch()
+{
+    if (d_scratch && cap_scratch * sizeof(u32) > arena_call()) {
+        (void)hipSetDevice(device);
+        (void)hipFree(d_scratch);
+        d_scratch = nullptr; cap_scratch = 0;
+    }
+}
+
 template <class T>
 static int grow(Ctx* ctx, T*& ptr, u64& cap, u64 need)
 {
@@ -308,9 +332,9 @@ static void parallel_for(size_t n, F fn)
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const unsigned nthr = n >= 8192 ? hw : 1;
     if (nthr == 1) { fn((size_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (unsigned k = 0; k < nthr; k++) th.emplace_back(fn, n * k / nthr, n * (k + 1) / nthr);
-    for (auto& t : th) t.join();
+    Threads pool;   // (the bodies passed here only index pre-sized arrays: they do not throw)
+    for (unsigned k = 0; k < nthr; k++) pool.start(fn, n * k / nthr, n * (k + 1) / nthr);
+    pool.join();
 }
 
 // ids (ascending on entry) -> stable order of decreasing key[id]; LSD radix sort, 3 passes of 11 bits (keys < 2^33)
@@ -569,34 +593,17 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     int rc_ = grow(this, d_results, cap_results, n + 1);  // + one dump slot for the padding tasks of the 4-task kernels
     if (rc_) return rc_;
     if (ops_total) { rc_ = grow(this, d_ops, cap_ops, ops_total); if (rc_) return rc_; }
-    rc_ = grow(this, d_tasks, cap_tasks, n + 256);
-    if (rc_) return rc_;
 
-    // arena budget
-    if (arena_limit == 0) {
-        size_t fr = 0, tot = 0;
-        HIPCHK(this, hipMemGetInfo(&fr, &tot));
-        arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.75);
-    }
+    // arena budget of THIS call: the context's budget over the contexts that share the device right now
+    if (arena_budget() == 0) { set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
+    const u64 arena_call = this->arena_call();
 
-    // pinned staging for the task upload and the result download (pageable copies cost ~20 ms per 60 k tasks)
-    if (n + 256 > cap_pinned) {
-        if (h_tasks) (void)hipHostFree(h_tasks);
-        if (h_results) (void)hipHostFree(h_results);
-        h_tasks = nullptr; h_results = nullptr; cap_pinned = 0;
-        const u64 want = n + n / 4 + 256;
-        if (hipHostMalloc(&h_tasks, want * sizeof(DevTask)) != hipSuccess ||
-            hipHostMalloc(&h_results, want * sizeof(DevResult)) != hipSuccess) {
-            set_error("hipHostMalloc of staging buffers failed");
-            return GAMDP_ENOMEM;
-        }
-        cap_pinned = want;
-    }
     u64 n_host_tasks = 0;
     std::vector<u64>& cells_key = w_key;
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
     struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; };
     std::vector<Launch> launches;
+    std::vector<std::vector<u32>> launch_items;   // the tasks of every launch, in launch order (staged once the plan is complete)
     // (Measured and dropped: handing the leftover of a multi-task group -- less than one round -- to a finer-grained kernel
     // as a launch of its own, and starting every other wavefront half a fill late to take the wavefronts of a launch of
     // equal tasks out of lock-step.  The first costs more than the stragglers do (launches are sequential), the second
@@ -633,7 +640,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             }
             const u64 dir_total = pair ? 2 * dirw : dirw;
             const u64 slotw = dir_total + 4ull * ypad * tpw + ckpt_words + bnd_words;
-            const u64 fit = arena_limit / (slotw * sizeof(u32));
+            const u64 fit = arena_call / (slotw * sizeof(u32));
             if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
             const u64 want = std::min<u64>((cur.size() + tpw - 1) / tpw, max_resident);
             if (fit < want && cur.size() > 1) {
@@ -647,7 +654,6 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             }
             Launch L;
             const size_t padded = (cur.size() + tpw - 1) / tpw * tpw;
-            if (n_host_tasks + padded > n + 256) { set_error("too many 4-task launches in one batch"); return GAMDP_ENOMEM; }
             L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)padded;
             L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
             // (Measured and dropped: equalising the rounds of a launch -- 6 250 workgroups as 2 x 3 125 instead of 4 096 +
@@ -657,15 +663,33 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             L.dyn_lds = 0;
             L.ckpt_off = ckpt_words ? dir_total + 4ull * ypad * tpw : 0;
             L.bnd_off = L.ckpt_off + ckpt_words;
-            {
-                DevTask* dst = h_tasks + n_host_tasks;
-                parallel_for(cur.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) dst[k] = prep[cur[k]].dt; });
-                // the last wavefront of a 4-task launch is filled up with copies of the last task that write to the dump slot
-                for (size_t k = cur.size(); k < padded; k++) { dst[k] = dst[cur.size() - 1]; dst[k].res_idx = (u32)n; dst[k].flags &= ~(u32)TF_WANT_OPS; }
-                n_host_tasks += padded;
-            }
+            n_host_tasks += padded;
+            launch_items.push_back(std::move(cur));
             launches.push_back(L);
         }
+    }
+    // Staging: the padded task list of all launches (the last wavefront of a multi-task launch is filled up with copies of
+    // its last task that write to the dump slot), sized from the finished plan -- however many launches the peeling made.
+    rc_ = grow(this, d_tasks, cap_tasks, n_host_tasks + 1);
+    if (rc_) return rc_;
+    // pinned staging for the task upload and the result download (pageable copies cost ~20 ms per 60 k tasks)
+    if (std::max<u64>(n_host_tasks, n) + 1 > cap_pinned) {
+        if (h_tasks) (void)hipHostFree(h_tasks);
+        if (h_results) (void)hipHostFree(h_results);
+        h_tasks = nullptr; h_results = nullptr; cap_pinned = 0;
+        const u64 base = std::max<u64>(n_host_tasks, n), want = base + base / 4 + 256;
+        if (hipHostMalloc(&h_tasks, want * sizeof(DevTask)) != hipSuccess ||
+            hipHostMalloc(&h_results, want * sizeof(DevResult)) != hipSuccess) {
+            set_error("hipHostMalloc of staging buffers failed");
+            return GAMDP_ENOMEM;
+        }
+        cap_pinned = want;
+    }
+    for (size_t li = 0; li < launches.size(); li++) {
+        const std::vector<u32>& cur = launch_items[li];
+        DevTask* dst = h_tasks + launches[li].first;
+        parallel_for(cur.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) dst[k] = prep[cur[k]].dt; });
+        for (size_t k = cur.size(); k < launches[li].count; k++) { dst[k] = dst[cur.size() - 1]; dst[k].res_idx = (u32)n; dst[k].flags &= ~(u32)TF_WANT_OPS; }
     }
     if (!launches.empty()) {
         u64 need_scratch = 0;
@@ -673,8 +697,18 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         if (need_scratch > cap_scratch) {
             if (d_scratch) { (void)hipFree(d_scratch); d_scratch = nullptr; cap_scratch = 0; }
             if (hipMalloc(&d_scratch, need_scratch * sizeof(u32)) != hipSuccess) {
-                set_error("hipMalloc of scratch arena (" + std::to_string(need_scratch * sizeof(u32)) + " bytes) failed");
-                return GAMDP_ENOMEM;
+                // a call on this context alone after calls that shared the device: its idle helper contexts may still
+                // hold their shares of the budget
+                d_scratch = nullptr;
+                (void)hipGetLastError();
+                if (arena_div == 1)
+                    for (Ctx* h : helpers)
+                        if (h->d_scratch) { (void)hipFree(h->d_scratch); h->d_scratch = nullptr; h->cap_scratch = 0; }
+                if (hipMalloc(&d_scratch, need_scratch * sizeof(u32)) != hipSuccess) {
+                    d_scratch = nullptr;
+                    set_error("hipMalloc of scratch arena (" + std::to_string(need_scratch * sizeof(u32)) + " bytes) failed");
+                    return GAMDP_ENOMEM;
+                }
             }
             cap_scratch = need_scratch;
         }
@@ -775,7 +809,9 @@ void gamdp_ctx_destroy(gamdp_ctx* ctx) { delete reinterpret_cast<Ctx*>(ctx); }
 int gamdp_ctx_set_arena_bytes(gamdp_ctx* ctx, uint64_t bytes)
 {
     if (!ctx) return GAMDP_EINVAL;
-    reinterpret_cast<Ctx*>(ctx)->arena_limit = bytes;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    c->arena_limit = bytes;                           // 0 = back to the automatic budget
+    for (Ctx* h : c->helpers) h->arena_limit = bytes; // (every call hands the owner's budget to its helpers again anyway)
     return 0;
 }
 
@@ -802,7 +838,7 @@ int gamdp_seqset_create(gamdp_ctx* ctx, const uint8_t* const* seqs, const uint64
     if (hipSetDevice(c->device) != hipSuccess) return GAMDP_EHIP;
     SeqSet* s = new (std::nothrow) SeqSet();
     if (!s) return GAMDP_ENOMEM;
-    const int rc_ = s->upload(c, seqs, lens, n, is_ascii != 0);
+    const int rc_ = guarded(c, [&] { return s->upload(c, seqs, lens, n, is_ascii != 0); });
     if (rc_) { delete s; return rc_; }
     *out = reinterpret_cast<gamdp_seqset*>(s);
     return 0;
@@ -830,6 +866,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     const SeqSet* sa = reinterpret_cast<const SeqSet*>(set_a);
     const SeqSet* sb = reinterpret_cast<const SeqSet*>(set_b);
+    return guarded(c, [&]() -> int {
     auto run = [&](Ctx* cc, size_t first, size_t cnt) -> int {
         if (cc->w_tasks.size() < cnt) cc->w_tasks.resize(cnt);
         std::vector<ITask>& it = cc->w_tasks;
@@ -867,26 +904,30 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         c->helpers.push_back(h);
     }
     Ctx* cc[2] = {c, c->helpers[0]};
-    if (c->arena_limit == 0) {   // the two contexts share the device: half the usual budget each
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->arena_limit = (u64)((double)(fr + c->cap_scratch * sizeof(u32)) * 0.75 * 0.5);
-    }
-    cc[1]->arena_limit = c->arena_limit;
+    // the two contexts share the device for this call: half the owner's budget each (the budget itself stays as it is)
+    if (c->arena_budget() == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
+    cc[1]->arena_limit = c->arena_limit; cc[1]->arena_share = c->arena_share;
+    struct DivGuard { Ctx* a; Ctx* b; ~DivGuard() { a->arena_div = 1; b->arena_div = 1; } } div_guard{cc[0], cc[1]};
+    cc[0]->arena_div = cc[1]->arena_div = 2;
+    cc[0]->trim_scratch(); cc[1]->trim_scratch();
     cc[1]->kernel_ms = 0; cc[1]->kernel_launches = 0;
     const size_t pieces = 4, per = (n + pieces - 1) / pieces;
     int rc[2] = {0, 0};
-    auto worker = [&](int t) {
+    auto worker = [&](int t) noexcept {
         for (size_t k = (size_t)t; k < pieces && rc[t] == 0; k += 2) {
             const size_t first = k * per, cnt = first < n ? std::min(per, n - first) : 0;
-            if (cnt) rc[t] = run(cc[t], first, cnt);
+            if (cnt) rc[t] = guarded(cc[t], [&] { return run(cc[t], first, cnt); });
         }
     };
-    std::thread th(worker, 1);
-    worker(0);
-    th.join();
+    {
+        Threads pool;   // joined on every path out
+        pool.start(worker, 1);
+        worker(0);
+    }
     c->kernel_ms += cc[1]->kernel_ms; c->kernel_launches += cc[1]->kernel_launches;
     if (rc[1]) c->set_error(cc[1]->err);
     return rc[0] ? rc[0] : rc[1];
+    });
 }
 
 int gamdp_task_preflight(uint64_t alen, uint64_t blen, uint32_t band, uint64_t begin_a, uint64_t end_a, uint64_t begin_b,
@@ -951,7 +992,7 @@ int gamdp_seqset_create_synth_strided(gamdp_ctx* ctx, uint64_t first_pair, uint6
     if (hipSetDevice(c->device) != hipSuccess) return GAMDP_EHIP;
     SeqSet* s = new (std::nothrow) SeqSet();
     if (!s) return GAMDP_ENOMEM;
-    const int rc_ = s->upload_synth(c, first_pair, stride_pairs, n_pairs, len);
+    const int rc_ = guarded(c, [&] { return s->upload_synth(c, first_pair, stride_pairs, n_pairs, len); });
     if (rc_) { delete s; return rc_; }
     *out = reinterpret_cast<gamdp_seqset*>(s);
     return 0;

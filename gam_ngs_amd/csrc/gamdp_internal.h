@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <new>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -78,7 +80,17 @@ struct Ctx {
     u32 max_lds_per_wg = 65536;
     hipStream_t stream = nullptr;
     std::string err;
+    // Scratch-arena budget.  arena_limit is THE budget of this context's device as its owner sees it: what
+    // gamdp_ctx_set_arena_bytes set, or -- while 0 -- 75 % of the free HBM at the first call.  It is never overwritten by
+    // a call.  What one align() call may claim is arena_limit / (arena_share * arena_div): arena_share = contexts a
+    // gamdp_multi handle created on this same device (set once by gamdp_multi_create), arena_div = contexts of THIS call
+    // that run at the same time on the device (the two of a chunked batch, the K cohorts of a merge-block call; set by
+    // the entry point for the duration of the call, which also hands the owner's budget to its helpers).
     u64 arena_limit = 0;
+    u32 arena_share = 1, arena_div = 1;
+    u64 arena_budget();   // determines the automatic budget on first use
+    u64 arena_call() const { return arena_limit / ((u64)(arena_share ? arena_share : 1) * (u64)(arena_div ? arena_div : 1)); }
+    void trim_scratch();  // gives back a scratch allocation larger than this call's share (before helper contexts allocate theirs)
 
     u32* d_scratch = nullptr; u64 cap_scratch = 0;  // in u32 words
     DevTask* d_tasks = nullptr; u64 cap_tasks = 0;
@@ -116,6 +128,32 @@ struct Fasta {
     std::vector<std::string> names;
     std::vector<std::vector<uint8_t>> codes;
     std::string err;
+};
+
+// Nothing may leave the C ABI as a C++ exception (the host program would std::terminate inside gam-merge instead of
+// falling back to its CPU path): the bodies of the entry points that allocate or start threads run under guarded(),
+// host threads are kept in a Threads object (joined on every path out), and thread bodies catch for themselves.
+template <class F>
+int guarded(Ctx* c, F&& f) noexcept
+{
+    auto note = [&](const char* what) noexcept { try { if (c) c->set_error(what); } catch (...) {} };
+    try { return f(); }
+    catch (const std::bad_alloc&) { note("out of host memory"); return GAMDP_ENOMEM; }
+    catch (const std::exception& e) { try { if (c) c->set_error(std::string("host exception: ") + e.what()); } catch (...) {} return GAMDP_EHIP; }
+    catch (...) { note("unknown host exception"); return GAMDP_EHIP; }
+}
+template <class F>
+int guarded_thread_body(F&& f) noexcept   // the return code of a thread body that must not throw
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { return GAMDP_ENOMEM; }
+    catch (...) { return GAMDP_EHIP; }
+}
+struct Threads {
+    std::vector<std::thread> th;
+    template <class... A> void start(A&&... a) { th.emplace_back(std::forward<A>(a)...); }
+    void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+    ~Threads() { join(); }
 };
 
 // deterministic longest-processing-time-first partition (gamdp_multi.cpp)

@@ -384,6 +384,7 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     const SeqSet* ss = reinterpret_cast<const SeqSet*>(slave);
     if (band > GAMDP_MAX_BAND) { c->set_error("band exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
     if (hipSetDevice(c->device) != hipSuccess) { c->set_error("hipSetDevice failed"); return GAMDP_EHIP; }
+    return guarded(c, [&]() -> int {
     const auto t_begin = std::chrono::steady_clock::now();
     std::vector<Machine> M(n);
     std::vector<u64> weight(n, 0);
@@ -416,9 +417,22 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     while ((int)c->helpers.size() < K - 1) {
         Ctx* h = new (std::nothrow) Ctx();
         if (!h || h->init(c->device) != 0) { c->set_error("helper context: " + (h ? h->err : std::string("out of memory"))); delete h; return GAMDP_ENODEV; }
-        h->arena_limit = c->arena_limit;
         c->helpers.push_back(h);
     }
+    // the K cohort contexts share the device for this call: 1/K of the owner's budget each, whatever was set or
+    // determined before (helpers that already exist included)
+    if (c->arena_budget() == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
+    struct DivGuard {
+        Ctx* c; int K;
+        ~DivGuard() { c->arena_div = 1; for (int k = 1; k < K; k++) c->helpers[(size_t)k - 1]->arena_div = 1; }
+    } div_guard{c, K};
+    c->arena_div = (u32)K;
+    for (int k = 1; k < K; k++) {
+        Ctx* h = c->helpers[(size_t)k - 1];
+        h->arena_limit = c->arena_limit; h->arena_share = c->arena_share; h->arena_div = (u32)K;
+        h->trim_scratch();
+    }
+    c->trim_scratch();
     std::vector<u32> part(n, 0);
     if (K > 1) partition_lpt(weight.data(), n, K, part.data());
     std::vector<std::vector<u32>> ids((size_t)K);
@@ -431,20 +445,19 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     std::unordered_map<u32, std::vector<uint8_t>> rc_cache;
     std::mutex rc_mu;
     const double k0_ms = c->kernel_ms; const u64 k0_n = c->kernel_launches;
-    auto body = [&](int k) {
+    auto body = [&](int k) noexcept {
         Ctx* cc = k == 0 ? c : c->helpers[(size_t)k - 1];
         if (k > 0) { cc->kernel_ms = 0; cc->kernel_launches = 0; cc->ref_event = c->ref_event; }
         cc->interval_sink = &intervals[(size_t)k];
-        run_cohort(cc, M, ids[(size_t)k], rc_cache, rc_mu, cst[(size_t)k]);
+        const int rc_k = guarded(cc, [&]() -> int { run_cohort(cc, M, ids[(size_t)k], rc_cache, rc_mu, cst[(size_t)k]); return 0; });
+        if (rc_k && !cst[(size_t)k].rc) cst[(size_t)k].rc = rc_k;
         cc->interval_sink = nullptr;
         if (k > 0) cc->ref_event = nullptr;  // borrowed
     };
-    if (K == 1) body(0);
-    else {
-        std::vector<std::thread> th;
-        for (int k = 1; k < K; k++) th.emplace_back(body, k);
+    {
+        Threads pool;   // joined on every path out, also when starting a later thread fails
+        for (int k = 1; k < K; k++) pool.start(body, k);
         body(0);
-        for (auto& t : th) t.join();
     }
     for (int k = 0; k < K; k++)
         if (cst[(size_t)k].rc) {
@@ -478,6 +491,7 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         std::fprintf(stderr, "gamdp_align_merge_blocks: %zu merge blocks, %d cohorts, %u rounds, %u launches: wall %.2f ms, GPU busy %.2f ms (kernels %.2f ms), pending %.2f ms, feed %.2f ms\n",
                      n, K, S.rounds, S.launches, S.wall_ms, S.gpu_busy_ms, S.kernel_sum_ms, S.host_pending_ms, S.host_feed_ms);
     return 0;
+    });
 }
 
 extern "C" int gamdp_ctx_l1_stats(const gamdp_ctx* ctx, gamdp_l1_stats* out)

@@ -58,11 +58,11 @@ int on_all_devices(Multi* m, F fn)
 {
     const size_t nd = m->ctxs.size();
     std::vector<int> rc(nd, 0);
-    if (nd == 1) rc[0] = fn((size_t)0);
+    auto body = [&](size_t d) noexcept { rc[d] = guarded(reinterpret_cast<Ctx*>(m->ctxs[d]), [&] { return fn(d); }); };
+    if (nd == 1) body(0);
     else {
-        std::vector<std::thread> th;
-        for (size_t d = 0; d < nd; d++) th.emplace_back([&, d] { rc[d] = fn(d); });
-        for (auto& t : th) t.join();
+        Threads pool;   // joined on every path out
+        for (size_t d = 0; d < nd; d++) pool.start(body, d);
     }
     for (size_t d = 0; d < nd; d++)
         if (rc[d]) {
@@ -101,6 +101,12 @@ int gamdp_multi_create(const int* devices, int n, gamdp_multi** out)
             return rc;
         }
         m->ctxs.push_back(c);
+    }
+    // a device listed more than once: its contexts split that device's scratch budget
+    for (int d = 0; d < n; d++) {
+        u32 same = 0;
+        for (int e = 0; e < n; e++) same += devices[e] == devices[d];
+        reinterpret_cast<Ctx*>(m->ctxs[(size_t)d])->arena_share = same;
     }
     *out = reinterpret_cast<gamdp_multi*>(m);
     return 0;
