@@ -27,6 +27,11 @@ The printed JSON line also carries
                   two-assembly workload: merge blocks/s, GCUPS, share of the call spent in GPU kernels, rounds;
   band150         the headline's own pairs once more at band 150, gam-merge's live band (N = 1, default workload only):
                   GCUPS, kernel, roofline fraction, and a sample verified against the CPU path like the headline's.
+  strong8_proxy   (and strong4_proxy) the share ONE GPU gets of the fixed list in a strong-scaling run at N = 8 (4) --
+                  pairs 0, 8, 16, ... -- timed on this GPU: GCUPS and projected_Ngpu_factor = N * gcups / value.  A
+                  one-GPU stand-in for the scaling curve the driver measures when it has an 8-GPU node; a sample is
+                  verified against the CPU path.
+roofline.valu is the secondary bound: the kernel is bound by vector-ALU issue, not by HBM.
 """
 import argparse
 import ctypes as C
@@ -151,6 +156,90 @@ def measured_traffic(P_launch, length, band, launches_ok, kernel):
     return tj["hbm_bytes_per_launch"], "profiles/" + name, tj.get("commit")
 
 
+PACKED_STREAM_CEILING_GCUPS = 20400.0   # tools/valu_rate5.hip: the bare packed-f16 cell stream on the whole chip
+
+
+def valu_record(P_launch, length, band, kernel, gcups):
+    """The secondary (binding) bound: vector-ALU instructions per cell update from the newest committed SQ_INSTS_VALU pass
+    of exactly this workload and kernel (replayed, like `traffic`), and this run's throughput against the measured
+    ceiling of the bare packed-f16 cell stream."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not name.endswith("_traffic.json"):
+            continue
+        try:
+            tj = json.load(open(os.path.join(pdir, name)))
+            cj = json.load(open(os.path.join(pdir, name.replace("_traffic.json", "_pmc_counters.json"))))
+            w = tj["workload"]
+            same_kernel = kernel.replace(" ", "").split("<")[0] + "<" in tj.get("kernel", "").replace(" ", "")
+            if (w["pairs_per_launch"], w["len"], w["band"]) == (P_launch, length, band) and same_kernel and "SQ_INSTS_VALU" in cj["counters"]:
+                best = (name.replace("_traffic.json", "_pmc_counters.json"), tj, cj)
+        except (OSError, KeyError, ValueError):
+            pass
+    rec = {"bound": "vector-ALU issue", "packed_stream_ceiling_gcups": PACKED_STREAM_CEILING_GCUPS,
+           "frac_of_valu_ceiling": gcups / PACKED_STREAM_CEILING_GCUPS, "insts_per_cell": None, "source": None,
+           "measured_in_this_run": False}
+    if best is not None:
+        name, tj, cj = best
+        cells = P_launch * (2 * band + 1) * length   # x_size * y_size per pair: the b window is the ~len-base slave
+        rec["insts_per_cell"] = cj["counters"]["SQ_INSTS_VALU"] * 64.0 / cells
+        rec["source"] = "profiles/%s @%s (SQ_INSTS_VALU x 64 lanes / cell updates of one launch)" % (name, tj.get("commit") or "unrecorded")
+    return rec
+
+
+def strided_sample(n_total, n_sample):
+    """Positions of a sample spread evenly over a list of n_total items (first and last included)."""
+    n = min(n_sample, n_total)
+    return sorted({round(j * (n_total - 1) / max(1, n - 1)) for j in range(n)}) if n_total else []
+
+
+def strong_proxy_record(ctx, n_gpus, pairs_total, length, band, value, steps=2, warmup=1, verify=128):
+    """Rank 0's share of the fixed list in a strong-scaling run over n_gpus GPUs (pairs 0, n_gpus, 2 n_gpus, ...: what
+    gamdp_partition_lpt deals it on equal weights), timed on this GPU."""
+    import gam_ngs_amd as gam
+    from gam_ngs_amd import lib as L
+    P = len(range(0, pairs_total, n_gpus))
+    sset = gam.SequenceSet.synthetic(ctx, 0, P, length, stride=n_gpus)
+    tasks = (L.Task * max(1, P))()
+    for k in range(P):
+        t = tasks[k]
+        t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, band
+        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, length - 1, 0, sset.lengths[2 * k + 1] - 1
+    out = (L.Result * max(1, P))()
+
+    def step():
+        rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
+        if rc != 0:
+            raise SystemExit("gamdp_align_batch (strong proxy) failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+
+    for _ in range(warmup):
+        step()
+    ctx.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    kernel_ms, launches = ctx.kernel_time()
+    cells = sum(out[k].cells for k in range(P))
+    if any(out[k].status != L.ST_OK for k in range(P)):
+        raise SystemExit("bench.py: strong proxy: pairs came back without an alignment")
+    gcups = cells / dt / 1e9
+    rec = {"pairs": P, "of": pairs_total, "gcups": gcups, "steps": steps, "ms_per_step": dt * 1e3,
+           "kernel_ms_per_launch": kernel_ms / max(1, launches), "launches": int(launches),
+           "projected_%dgpu_factor" % n_gpus: n_gpus * gcups / value if value else None,
+           "note": "one GPU's share of the strong-scaling list at N = %d, measured on ONE GPU; not a multi-GPU measurement" % n_gpus}
+    if verify:
+        pos = strided_sample(P, verify)
+        cpu, cpu_keys = cpu_baseline(length, band, [k * n_gpus for k in pos])
+        diff = [j for j, k in enumerate(pos) if tuple(out[k].key()) != tuple(cpu_keys[j])]
+        if diff:
+            raise SystemExit("bench.py: strong proxy: GPU result of pair %d differs from the CPU %s" % (pos[diff[0]] * n_gpus, cpu["kind"]))
+        rec["verified_pairs"] = len(pos)
+    sset.close()
+    return rec
+
+
 def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
     """The pairs of the headline run (still resident) aligned at band 150, gam-merge's only live band
     (banded_smith_waterman.hpp:38): the "band150" object of the line.  `verify` pairs are compared with the CPU path."""
@@ -182,14 +271,15 @@ def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
            "kernel": kernel_name(band, P, length), "kernel_ms_per_launch": per_launch_s * 1e3, "launches": int(launches),
            "roofline_frac": (cells * steps / max(1, launches)) * B_ALG / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s > 0 else 0.0}
     if verify:
-        n = min(verify, P)
-        ids = [m["first"] + k * m["stride"] for k in range(n)]
+        pos = strided_sample(P, verify)   # spread over the whole list (its order is also the launch's pairing order)
+        ids = [m["first"] + k * m["stride"] for k in pos]
         cpu, cpu_keys = cpu_baseline(length, band, ids)
-        diff = [k for k in range(n) if tuple(out[k].key()) != tuple(cpu_keys[k])]
+        diff = [j for j, k in enumerate(pos) if tuple(out[k].key()) != tuple(cpu_keys[j])]
         if diff:
             raise SystemExit("bench.py: band 150: GPU result of pair %d differs from the CPU %s: %r vs %r"
-                             % (ids[diff[0]], cpu["kind"], out[diff[0]].key(), cpu_keys[diff[0]]))
-        rec["verified_pairs"] = n
+                             % (ids[diff[0]], cpu["kind"], out[pos[diff[0]]].key(), cpu_keys[diff[0]]))
+        rec["verified_pairs"] = len(pos)
+        rec["verified_sample"] = "every %d-th pair of the list" % max(1, (P - 1) // max(1, len(pos) - 1))
     for k in range(P):
         tasks[k].band = 512
     return rec
@@ -224,6 +314,7 @@ def main():
     ap.add_argument("--no-l1", action="store_true", help="skip the merge-block (L1, band 150) record")
     ap.add_argument("--l1-genome", type=int, default=2_900_000, help="genome size of the L1 workload (S. aureus: 2.9 Mb)")
     ap.add_argument("--no-band150", action="store_true", help="skip the band-150 record of the same pairs")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the strong8_proxy / strong4_proxy records")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -328,7 +419,11 @@ def main():
         line = {
             "metric": "GCUPS", "value": m["gcups"], "unit": "GCUPS", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": m["dt_max"] / steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": ("int32 (fast blocks: exact packed-f16 offsets from per-lane int32 bases, two tasks per register; "
+                      "results bit-identical to the reference's int64 DP)") if kname.startswith(("k_align_p", "k_align_o"))
+                     else "int32 (results bit-identical to the reference's int64 DP)",
+            "data": "synthetic",
             "config": {"workload": "synthetic %d bp x ~%d bp contig pairs, 5%% divergence, band %d "
                                    "(BASELINE.json config 5 generator), find_alignment incl. traceback summary"
                                    % (length, length, band),
@@ -341,13 +436,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / avg_launch_s / 1e9) if traffic_bytes and avg_launch_s > 0 else None,
-                         "traffic_bytes_per_launch": traffic_bytes,
+                         "traffic_bytes_per_launch": traffic_bytes, "traffic_measured_in_this_run": False,
                          "traffic_source": ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                             "workload, collected at commit %s), divided by this run's kernel time"
                                             % (traffic_src, traffic_commit or "unrecorded")) if traffic_src else None,
                          "algorithmic_bytes_per_launch": cells_per_launch * B_ALG,
                          "kernel": kname, "kernel_ms_per_launch": avg_launch_s * 1e3,
-                         "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG},
+                         "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG,
+                         "valu": valu_record(m["P"], length, band, kname, m["gcups"]) if world == 1 else None},
         }
         if weak is not None:
             line["weak"] = weak
@@ -355,18 +451,31 @@ def main():
             raise SystemExit("bench.py: %d pairs came back without an alignment" % int(m["bad_all"]))
         if not args.no_cpu_baseline and world == 1:
             n_cpu = min(args.cpu_pairs or 32 * min(os.cpu_count() or 1, 16), m["P"])
-            ids = [m["first"] + k * m["stride"] for k in range(n_cpu)]
+            # the sample is spread over the whole list (the list order is also the order in which a launch pairs tasks
+            # up); only the oracle's own bench entry ("port", no reference build on this box) needs a contiguous range
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle as O
+            pos = strided_sample(m["P"], n_cpu) if O.ref() is not None else list(range(n_cpu))
+            ids = [m["first"] + k * m["stride"] for k in pos]
             rec, cpu_keys = cpu_baseline(length, band, ids)
             line["cpu_baseline"] = rec
-            gpu_keys = m["gpu_keys"](n_cpu)
-            diff = [k for k in range(n_cpu) if tuple(gpu_keys[k]) != tuple(cpu_keys[k])]
+            all_keys = m["gpu_keys"](m["P"])
+            gpu_keys = [all_keys[k] for k in pos]
+            diff = [j for j in range(len(pos)) if tuple(gpu_keys[j]) != tuple(cpu_keys[j])]
             if diff:
                 k = diff[0]
                 raise SystemExit("bench.py: GPU result of pair %d differs from the CPU %s: %r vs %r (%d of %d differ)"
-                                 % (ids[k], rec["kind"], gpu_keys[k], cpu_keys[k], len(diff), n_cpu))
-            line["verified_pairs"] = n_cpu   # status, begin, score, #matches, length, first/last match, identity
+                                 % (ids[k], rec["kind"], gpu_keys[k], cpu_keys[k], len(diff), len(pos)))
+            line["verified_pairs"] = len(pos)   # status, begin, score, #matches, length, first/last match, identity
+            line["verified_sample"] = "every %d-th pair of the list" % max(1, (m["P"] - 1) // max(1, len(pos) - 1))
         if not args.no_band150 and world == 1 and band == 512 and "_keep" in m:
             line["band150"] = band150_record(ctx, m, length, verify=0 if args.no_cpu_baseline else 128)
+        if not args.no_proxy and world == 1 and band == 512 and args.scaling == "strong" and args.pairs >= 64:
+            if "_keep" in m:
+                m["_keep"][0].close()   # the headline's sequences: make room
+            for ng in (8, 4):
+                line["strong%d_proxy" % ng] = strong_proxy_record(ctx, ng, args.pairs, length, band, m["gcups"],
+                                                                  verify=0 if args.no_cpu_baseline else 128)
         if not args.no_l1 and world == 1:
             import bench_l1
             line["l1"] = bench_l1.run(ctx, genome=args.l1_genome)

@@ -83,8 +83,12 @@ def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150):
     }
     if verify:
         from _l1oracle import oracle_mb
-        # the cheapest merge blocks keep the CPU check to seconds; every decision field is compared
-        order = sorted(range(n), key=lambda i: sum(b[1] - b[0] for b in flat[i]["blocks"]))[:verify]
+        # a sample across the whole size distribution (every (n-1)/(verify-1)-th merge block of the list sorted by block
+        # span: the cheapest, the largest -- multi-round retries, tails, the long band-150 calls -- and what lies
+        # between); every decision field is compared
+        by_span = sorted(range(n), key=lambda i: sum(b[1] - b[0] for b in flat[i]["blocks"]))
+        k = min(verify, n)
+        order = sorted({by_span[round(j * (n - 1) / max(1, k - 1))] for j in range(k)}) if n else []
         for i in order:
             mb = flat[i]
             sc = dict(master=_gage.to_ascii(pb["master"][mb["m_id"]]["seq"]).decode(),
@@ -98,6 +102,7 @@ def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150):
             if got != want:
                 raise SystemExit("bench_l1: merge block %d differs from the CPU oracle: %r vs %r" % (i, got, want))
         rec["verified_merge_blocks"] = len(order)
+        rec["verified_sample"] = "every %d-th merge block of the list sorted by block span, smallest and largest included" % max(1, (n - 1) // max(1, k - 1))
     masters.close()
     slaves.close()
     return rec

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "gamdp_dev.h"
 

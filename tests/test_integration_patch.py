@@ -55,3 +55,25 @@ def test_patch_applies_cleanly_to_the_reference(tmp_path):
     assert "ThreadedBuildPctg::runOnGpu()" in tb and "if( gamdp_bridge::ready() ) return this->runOnGpu();" in tb
     assert "gamdp_bridge::init( masterCodes, slaveCodes );" in open(tree / "src/Merge.cc").read()
     assert "GamdpBridge.cc" in open(tree / "CMakeLists.txt").read()
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "lib", "src", "pctg")), reason="reference tree not present")
+def test_make_l1_dump_script_first_half(tmp_path):
+    """integration/make_l1_dump.sh up to where a Boost host is needed: a patched copy of the reference, the stand-in
+    library for hosts without hipcc (exports what the bridge binds, refuses every call), the bridge compiled and linked
+    against it with no undefined symbol.  The rest (cmake, gam-merge with GAMDP_DUMP_PREFIX, the copy into
+    tests/golden/l1_reference_dump/) cannot run here."""
+    env = dict(os.environ, TMPDIR=str(tmp_path), GAMDP_FORCE_STUB="1")
+    r = subprocess.run(["bash", os.path.join(ROOT, "integration", "make_l1_dump.sh"), REF, "selftest", str(tmp_path / "no_example"), "--check-only"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "bridge compiles and links" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert not os.path.exists(os.path.join(ROOT, "tests", "golden", "l1_reference_dump", "selftest"))
+    # the stand-in refuses: the bridge then leaves gam-merge on its CPU path
+    so = tmp_path / "stub.so"
+    assert subprocess.run(["gcc", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o", str(so),
+                           os.path.join(ROOT, "integration", "gamdp_stub.c")]).returncode == 0
+    import ctypes
+    stub = ctypes.CDLL(str(so))
+    h = ctypes.c_void_p()
+    dev = (ctypes.c_int * 1)(0)
+    assert stub.gamdp_multi_create(dev, 1, ctypes.byref(h)) != 0 and not h.value

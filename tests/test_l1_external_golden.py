@@ -103,12 +103,21 @@ def test_harness_on_a_dump_written_from_the_oracle(tmp_path):
     assert D.read_dump(os.path.join(d, "dump"))[0]["blocks"] == [tuple(b) for b in recs[0]["blocks"]]
     n, bad = check_oracle(d)
     assert n == len(recs) >= 10 and not bad
-    # a wrong coordinate in the dump is caught
+    # The harness would catch a misreading of PctgBuilder.cc: a dump that deviates from ours in ONE field of ONE merge
+    # block fails, whichever field it is -- an off-by-one end coordinate, the orientation, the verdict, a throw.
+    import copy
     k = next(i for i, r in enumerate(recs) if r["out"]["align_ok"])
-    recs[k]["out"]["m_end"] += 1
+    k_rev = next((i for i, r in enumerate(recs) if r["out"]["align_ok"] and r["out"]["align_rev"]), k)
+    for field, idx, change in (("m_end", k, lambda v: v + 1), ("m_end", k, lambda v: v - 1), ("s_start", k, lambda v: v + 1),
+                               ("align_rev", k, lambda v: 1 - int(v)), ("align_rev", k_rev, lambda v: 1 - int(v)),
+                               ("align_ok", k, lambda v: 1 - int(v)), ("thrown", k, lambda v: 1)):
+        bent = copy.deepcopy(recs)
+        bent[idx]["out"][field] = change(bent[idx]["out"][field])
+        D.write_dump(os.path.join(d, "dump"), bent)
+        n, bad = check_oracle(d)
+        assert [b[0] for b in bad] == [idx], (field, idx, bad[:3])
     D.write_dump(os.path.join(d, "dump"), recs)
-    n, bad = check_oracle(d)
-    assert [b[0] for b in bad] == [k]
+    assert check_oracle(d)[1] == []
 
 
 @pytest.mark.gpu
@@ -116,3 +125,11 @@ def test_gpu_harness_on_a_dump_written_from_the_oracle(tmp_path):
     d, recs = synthetic_dataset(tmp_path)
     n, bad = check_gpu(d)
     assert n == len(recs) and not bad, bad[:3]
+    # ... and the GPU half of the harness catches a flipped orientation and an off-by-one end just the same
+    k = next(i for i, r in enumerate(recs) if r["out"]["align_ok"])
+    for field, change in (("align_rev", lambda v: 1 - int(v)), ("m_end", lambda v: v + 1)):
+        bent = [dict(r, out=dict(r["out"])) for r in recs]
+        bent[k]["out"][field] = change(bent[k]["out"][field])
+        D.write_dump(os.path.join(d, "dump"), bent)
+        n, bad = check_gpu(d)
+        assert [b[0] for b in bad] == [k], (field, bad[:3])

@@ -1,0 +1,19 @@
+# round 3, probe 2: software-pipelined packed fill -- parity first, then the size sweep
+mkdir -p gpurun_out/r03_probe2
+timeout 900 python -m pytest tests/test_gpu_l0_parity.py tests/test_gpu_fullsize_properties.py -x -q -m gpu > gpurun_out/r03_probe2/pytest.log 2>&1; tail -3 gpurun_out/r03_probe2/pytest.log
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150"
+run() { name=$1; shift; $B "$@" > gpurun_out/r03_probe2/$name.log 2>&1; python - gpurun_out/r03_probe2/$name.log $name <<'PY'
+import json,sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d=json.loads(l); print("%-22s gcups %.0f kernel_ms %.1f ms_step %.1f kernel %s"%(sys.argv[2], d["value"], d["roofline"]["kernel_ms_per_launch"], d["ms_per_step"], d["roofline"]["kernel"]))
+PY
+}
+run b512_100k
+run b512_25000 --pairs 25000
+run b512_12500 --pairs 12500
+run b512_8192 --pairs 8192
+run b512_4096 --pairs 4096
+run b512_2048 --pairs 2048
+run b150_100k --band 150
+run b150_12500 --band 150 --pairs 12500
