@@ -324,6 +324,9 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     constexpr bool HASN = false;
     const DevTask& da = p.tasks[2 * qi];
     const DevTask& db = p.tasks[2 * qi + 1];
+#ifdef GAMDP_EXP_HWID
+    const long long exp_t0 = wall_clock64();
+#endif
     // slot: [dir A][dir B][side buffers A][side buffers B][packed rows][packed boundaries]
     u32* const sideA = slot + 2 * p.dir_words;
     Tk ta = make_tk(da, p, slot, sideA, slot);
@@ -351,7 +354,15 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     // (two tasks that share no usable run of fast blocks were each filled with directions: they are walked as they are)
     // end cells, walks, results: one task after the other in long launches, where the scalar walk of one wavefront hides
     // behind the fills of its SIMD's other wavefronts; side by side in launches of at most two rounds (LP_WALK_SIDE_BY_SIDE)
+#ifdef GAMDP_EXP_HWID
+    const long long exp_t1 = wall_clock64();
+#endif
     finish_many<C, CE, HASN, true, 2, 64>(p, 2 * qi, ta, tb, lane, (p.flags & LP_WALK_SIDE_BY_SIDE) != 0);
+#ifdef GAMDP_EXP_HWID
+    // placement experiment (results unusable): task A's record carries when the pair started and when its fill ended
+    if (lane == 0) { DevResult* r = &p.results[da.res_idx]; r->begin_a = (int)(exp_t0 & 0x7fffffff); r->begin_b = (int)(exp_t1 & 0x7fffffff); r->score = 12345; }
+    __syncthreads();
+#endif
 }
 
 #ifndef GAMDP_PAIR_WAVES_PER_SIMD

@@ -26,6 +26,7 @@ SYMBOLS = [
 
 EINVAL, ENODEV, ENOMEM, ENOTSUP, EHIP = -1, -2, -3, -4, -5
 ST_OK, ST_EMPTY, ST_OUT_OF_RANGE, ST_INVALID = 0, 1, 2, 3
+ST_DIAG_RANGE = 9   # diagnostics build only: a packed-f16 block left the exact range (never expected)
 
 
 class GamdpError(RuntimeError):

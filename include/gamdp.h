@@ -49,6 +49,9 @@ extern "C" {
 #define GAMDP_ST_OUT_OF_RANGE 2 /* reference throws std::out_of_range from Contig::at; gam-merge then
                                    drops the whole graph (lib/src/pctg/ThreadedBuildPctg.cc:322-329)   */
 #define GAMDP_ST_INVALID      3 /* arguments for which the reference has undefined behaviour           */
+#define GAMDP_ST_DIAG_RANGE   9 /* libgamdp_diag.so only (never the product library): a packed-f16 block of this task held
+                                   a value outside the exactly representable range -- the assertion behind the range argument
+                                   of DESIGN.md section 4; the parity campaigns run on that build and expect none           */
 
 /* edit-string alphabet (lib/include/alignment/my_alignment.hpp:57-62) */
 #define GAMDP_OP_GAP_A 0

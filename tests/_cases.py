@@ -118,3 +118,68 @@ def beyond_cases(seed, n, bands=(0, 1, 5, 20, 150), max_len=120):
         out.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=begin_a, end_a=end_a, begin_b=begin_b,
                         end_b=end_b, fs=rng.random() < 0.3, fe=rng.random() < 0.4))
     return out
+
+
+# ---- adversarial long pairs: built to attack the exactness argument of the packed-f16 blocks -- the
+# value ranges a lane and a block can span, ties everywhere, paths hugging the band edges.  Deterministic in (kind, n, band).
+ADVERSARIAL_KINDS = ("homopolymer", "ac_shift1", "ac_vs_ag", "unrelated", "complement", "ins400_b", "ins400_a",
+                     "ins_past_band_b", "ins_past_band_a", "div50", "tandem17", "tandem19")
+
+
+def adversarial_pair(kind, n, band):
+    """(a, b) ASCII strings of about n bases."""
+    rng = random.Random(zlib_seed(kind, n, band))
+    comp = {"A": "T", "T": "A", "C": "G", "G": "C"}
+    if kind == "homopolymer":
+        return "A" * n, "A" * (n - n // 50)
+    if kind == "ac_shift1":
+        return "AC" * (n // 2), ("AC" * (n // 2 + 1))[1:n - 3]
+    if kind == "ac_vs_ag":
+        return "AC" * (n // 2), "AG" * (n // 2)
+    if kind == "unrelated":
+        return rand_seq(rng, n), rand_seq(rng, n)
+    if kind == "complement":   # every column of the main diagonal mismatches
+        a = rand_seq(rng, n)
+        return a, "".join(comp[c] for c in a)
+    if kind in ("ins400_b", "ins400_a", "ins_past_band_b", "ins_past_band_a"):
+        # one long indel early on: the path runs along (400) or is pinned against (band + 40) a band edge from there on
+        a = rand_seq(rng, n)
+        b = mutate(rng, a, 0.02, 0.002, 0.002)
+        k = 400 if kind.startswith("ins400") else band + 40
+        at = n // 10
+        if kind.endswith("_b"):
+            b = b[:at] + rand_seq(rng, k) + b[at:]
+        else:
+            a = a[:at] + rand_seq(rng, k) + a[at:]
+        return a, b
+    if kind == "div50":
+        a = rand_seq(rng, n)
+        return a, mutate(rng, a, 0.30, 0.10, 0.10)
+    if kind in ("tandem17", "tandem19"):   # periods = the columns a lane owns at band 512 / in the band-150 throughput kernels
+        p = 17 if kind == "tandem17" else 19
+        unit = rand_seq(rng, p)
+        a = (unit * (n // p + 1))[:n]
+        b = mutate(rng, a, 0.01, 0.003, 0.003)
+        return a, b[p // 2:]
+    raise ValueError(kind)
+
+
+def zlib_seed(kind, n, band):
+    import zlib
+    return zlib.crc32(("%s/%d/%d" % (kind, n, band)).encode())
+
+
+def adversarial_specs():
+    """(kind, n, band) of every committed adversarial vector: 3-20 kb at band 512, 6-20 kb at band 150."""
+    out = []
+    for i, kind in enumerate(ADVERSARIAL_KINDS):
+        out.append((kind, (3000, 8000, 20000)[i % 3], 512))
+        out.append((kind, (12000, 3500)[i % 2], 512))
+        out.append((kind, (6000, 12000, 20000)[(i + 1) % 3], 150))
+        out.append((kind, (9000, 6500)[i % 2], 150))
+    return out
+
+
+def adversarial_case(kind, n, band):
+    a, b = adversarial_pair(kind, n, band)
+    return dict(a=a.encode(), b=b.encode(), band=band, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False)

@@ -36,3 +36,15 @@ def l0_cases():
                      begin_b=d["begin_b"], end_b=d["end_b"], fs=d["fs"], fe=d["fe"])
             out.append((d["name"], c, d["expect"]))
     return out
+
+
+def adversarial_cases():
+    """(spec dict, case-dict-with-bytes, expect) of tests/golden/l0_adversarial.json: the inputs are rebuilt from the recipe
+    (tests/_cases.py adversarial_pair) and checked against the CRC32 the generator recorded."""
+    import _cases
+    out = []
+    for d in load("l0_adversarial.json"):
+        c = _cases.adversarial_case(d["kind"], d["n"], d["band"])
+        assert (len(c["a"]), len(c["b"]), zlib.crc32(c["a"]), zlib.crc32(c["b"])) == (d["a_len"], d["b_len"], d["a_crc32"], d["b_crc32"]), d["kind"]
+        out.append((d, c, d["expect"]))
+    return out

@@ -11,6 +11,10 @@ source text.  Files written next to this script:
   l0_handbuilt.json   SURVEY Appendix D checklist items 1-9, 11, 14 (named cases)
   l0_random.json      600 seeded random windowed cases (tests/_cases.py, seed 2024)
   l0_large.json       synthetic 50 kb pairs (generator = gamdp_oracle_synth_pair, keys stored)
+  l0_adversarial.json 48 long adversarial pairs (tests/_cases.py adversarial_pair: homopolymers, dinucleotide repeats,
+                      unrelated / complementary / 50 %-diverged sequences, long indels that pin the path to a band edge,
+                      tandem repeats of the lane widths) at bands 512 and 150: recipe + CRC32 of the inputs, the
+                      reference's summary and the CRC32 of its edit string
   findhits.json       ABlast::findHits cases (checklist item 10)
   seqops.json         normalisation + reverse_complement cases (items 7, 13)
   fasta.json          FASTA files and what the reference's readNextContigID/readNextSequence load from them
@@ -153,6 +157,15 @@ def large():
     return out
 
 
+def adversarial():
+    out = []
+    for kind, n, band in _cases.adversarial_specs():
+        c = _cases.adversarial_case(kind, n, band)
+        out.append(dict(kind=kind, n=n, band=band, a_len=len(c["a"]), b_len=len(c["b"]), a_crc32=zlib.crc32(c["a"]),
+                        b_crc32=zlib.crc32(c["b"]), expect=expect(c)))
+    return out
+
+
 def findhits():
     rng = random.Random(99)
     out = []
@@ -237,18 +250,23 @@ def fasta():
 
 def main():
     assert O.ref() is not None, "needs /root/reference"
+    only = sys.argv[1:]   # e.g. `make_golden.py l0_adversarial.json` regenerates that file alone
 
-    def dump(name, obj):
+    def dump(name, make):
+        if only and name not in only:
+            return
+        obj = make()
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(obj, f, indent=0, sort_keys=True)
         print(name, len(obj))
 
-    dump("l0_handbuilt.json", handbuilt())
-    dump("l0_random.json", [jcase("r%d" % i, c) for i, c in enumerate(_cases.cases(2024, 600))])
-    dump("l0_large.json", large())
-    dump("findhits.json", findhits())
-    dump("seqops.json", seqops())
-    dump("fasta.json", fasta())
+    dump("l0_handbuilt.json", handbuilt)
+    dump("l0_random.json", lambda: [jcase("r%d" % i, c) for i, c in enumerate(_cases.cases(2024, 600))])
+    dump("l0_large.json", large)
+    dump("l0_adversarial.json", adversarial)
+    dump("findhits.json", findhits)
+    dump("seqops.json", seqops)
+    dump("fasta.json", fasta)
 
 
 if __name__ == "__main__":

@@ -148,6 +148,69 @@ def test_golden_large_synthetic_pairs():
                 G.check_ops(d["expect"], r.ops)
 
 
+def _adversarial_batches():
+    """The reference-generated adversarial vectors arranged so that the multi-task kernels pack them: (1) all of them,
+    neighbours in the launch's longest-first order = adversarial with adversarial; (2) every one next to an ordinary
+    related pair with exactly as many rows (equal predicted cells keep the caller's order: they share a wavefront)."""
+    items = G.adversarial_cases()
+    rng = random.Random(77)
+    mixed = []
+    for d, c, e in items:
+        a = _cases.rand_seq(rng, len(c["a"]))
+        b = (_cases.mutate(rng, a) + _cases.rand_seq(rng, 64))[:len(c["b"])]
+        mixed.append((d, c, e))
+        mixed.append((None, dict(a=a.encode(), b=b.encode(), band=c["band"], begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1,
+                                 fs=False, fe=False), None))
+    return items, mixed
+
+
+def test_adversarial_golden_vectors_through_the_packed_kernels():
+    """low-complexity, unrelated and band-edge-hugging pairs of 3-20 kb are what the range argument of
+    the packed-f16 blocks has to survive.  Band 512 runs two tasks per wavefront here (k_align_p); band 150 takes the
+    eight-task kernel in the child process below (GAMDP_QUAD_MIN=1).  Summaries and edit-string CRCs are the reference's."""
+    items, mixed = _adversarial_batches()
+    assert len(items) % 2 == 0
+    for batch in (items, mixed):
+        cases = [c for _, c, _ in batch]
+        for want_ops in (False, True):
+            res = run_cases(cases, want_ops=want_ops)
+            for (d, c, e), r in zip(batch, res):
+                if e is None:     # the ordinary partner: against the oracle
+                    o, ops = oracle_for(c, want_ops)
+                    assert r.key() == o.key() and (not want_ops or r.ops == ops), ("partner", c["band"], len(c["a"]))
+                    continue
+                assert r.key() == G.expect_key(e), (d["kind"], d["n"], d["band"], r.key(), G.expect_key(e))
+                if want_ops:
+                    G.check_ops(e, r.ops)
+
+
+def test_adversarial_golden_vectors_eight_and_four_task_kernels_in_a_fresh_process():
+    """The same vectors with every band-150 call forced through the eight-task packed kernel (k_align_o)."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_QUAD_MIN"):
+        pytest.skip("already inside the child")
+    env = dict(os.environ, GAMDP_QUAD_MIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "adversarial_golden_vectors_through"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
+def test_range_assertion_of_the_packed_blocks_in_the_diagnostics_build():
+    """libgamdp_diag.so checks, before every re-centring of a packed-f16 block, that each live value lies inside +-2040
+    (kernel_pair.inc) and reports a violation as GAMDP_ST_DIAG_RANGE (9) -- which no expected result carries.  The
+    adversarial vectors, the long synthetic pairs, the unequal partners and the strip stress cases run on that build,
+    at band 512 through the two-task kernel and (GAMDP_QUAD_MIN=1) at band 150 through the eight-task kernel."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_LIB"):
+        pytest.skip("already inside a child with a chosen library")
+    for extra in ({}, {"GAMDP_QUAD_MIN": "1"}):
+        env = dict(os.environ, GAMDP_LIB=DIAG_LIB, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                            "adversarial_golden_vectors_through or golden_large or pairs_of_unequal or direction_free or band150_stress_cases"],
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
 def test_reverse_complement_and_suffix_views():
     """a_rc / b_rc / *_off must equal aligning explicitly reverse-complemented / chopped copies."""
     rng = random.Random(31)

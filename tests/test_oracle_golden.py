@@ -38,6 +38,18 @@ def test_l0_large_synthetic(idx):
     assert r.cells == min(sl, d["len"] + d["band"]) * (2 * d["band"] + 1)
 
 
+def test_l0_adversarial_long_pairs():
+    """48 reference-generated long pairs built against the value-range argument of the packed-f16 blocks (homopolymers,
+    dinucleotide repeats, unrelated / complementary / half-diverged sequences, indels that pin the path to a band edge,
+    tandem repeats of the lane widths): the restatement first."""
+    items = G.adversarial_cases()
+    assert len(items) >= 48 and {d["band"] for d, _, _ in items} == {150, 512}
+    for d, c, e in items:
+        r, ops = O.oracle_align(O.encode(c["a"]), O.encode(c["b"]), c["band"], c["begin_a"], c["end_a"], c["begin_b"], c["end_b"])
+        assert r.key() == G.expect_key(e), (d["kind"], d["n"], d["band"])
+        G.check_ops(e, ops)
+
+
 def test_find_hits():
     for d in G.load("findhits.json"):
         got = O.oracle_find_hits(O.encode(d["a"]), d["a_s"], d["a_e"], O.encode(d["b"]), d["b_s"], d["b_e"], d["word"])

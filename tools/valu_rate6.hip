@@ -15,14 +15,15 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2 as_h2(u32 x) { return __builtin_bit_cast(h2, x); }
 __device__ __forceinline__ u32 as_u(h2 x) { return __builtin_bit_cast(u32, x); }
 constexpr int C = 17, ROWS = 16;
-__shared__ u32 s_tab[2][2048 + 16];
-__shared__ u32 s_w[2048 + 16];
+constexpr int TN = 256;   // (small tables: 3 KB of LDS per wavefront, so that 5 wavefronts per SIMD fit a CU)
+__shared__ u32 s_tab[2][TN + 16];
+__shared__ u32 s_w[TN + 16];
 
 template <int V>
-__global__ __launch_bounds__(64, 4) void k(u32* out, const u32* in, int blocks16)
+__global__ __launch_bounds__(64, 5) void k(u32* out, const u32* in, int blocks16)
 {
     const int lane = threadIdx.x;
-    for (int i = lane; i < 2048 + 16; i += 64) { s_tab[0][i] = in[i]; s_tab[1][i] = in[i + 4096]; s_w[i] = in[i + 8192]; }
+    for (int i = lane; i < TN + 16; i += 64) { s_tab[0][i] = in[i]; s_tab[1][i] = in[i + 4096]; s_w[i] = in[i + 8192]; }
     __syncthreads();
     u32 Lp[C], W[C + ROWS - 1];
 #pragma unroll
@@ -32,9 +33,9 @@ __global__ __launch_bounds__(64, 4) void k(u32* out, const u32* in, int blocks16
     u32 Lin = in[lane + 7], xk = in[lane + 9], dl = in[lane + 11], dr = in[lane + 13];
     const h2 three = {(_Float16)3.0f, (_Float16)3.0f};
     for (int b = 0; b < blocks16; ++b) {
-        const u32* ta = &s_tab[0][(b * 16 + lane) & 2047];
-        const u32* tb = &s_tab[1][(b * 16 + lane) & 2047];
-        const u32* wa = &s_w[(b * 16 + 3 * lane) & 2047];
+        const u32* ta = &s_tab[0][(b * 16 + lane) & (TN - 1)];
+        const u32* tb = &s_tab[1][(b * 16 + lane) & (TN - 1)];
+        const u32* wa = &s_w[(b * 16 + 3 * lane) & (TN - 1)];
         if constexpr (V == 1) {
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
@@ -133,7 +134,7 @@ int main()
     (void)hipMalloc(&out, 256 * 32 * 64 * 4);
     (void)hipMalloc(&in, 1 << 20);
     (void)hipMemset(in, 0x11, 1 << 20);
-    for (int w = 1; w <= 4; ++w) {
+    for (int w = 1; w <= 5; ++w) {
         run<1>("source order (round 2)", out, in, w);
         run<2>("software-pipelined", out, in, w);
     }
