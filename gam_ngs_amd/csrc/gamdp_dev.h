@@ -75,6 +75,11 @@ struct LaunchParams {
     u64 ckpt_off;          // word offsets inside a slot of the direction-free fill's row / boundary stores
     u64 bnd_off;           // (0 = this launch keeps directions everywhere)
     u32 flags;             // LP_*
+    // Issue priority by remaining work (kernel_common.inc, set_prio_by_remaining): the units (tasks / pairs / quads / octets)
+    // from index prio_from on raise their wavefront's s_setprio level while they have many blocks left, measured against
+    // prio_R = the block count of the launch's largest task (0 = off).  The host switches it on for the units that are in
+    // flight when the queue runs dry: all of a launch of at most two rounds, the last n_slots of a longer one.
+    u32 prio_R, prio_from;
 };
 // the two-task kernel walks its two tasks side by side (kernel_walk.inc) instead of one after the other: set by the host for
 // launches of at most two rounds, where the wavefronts of a SIMD walk at the same time and the scalar unit is the bottleneck

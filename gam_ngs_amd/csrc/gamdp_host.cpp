@@ -737,6 +737,12 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
             static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::atol(e) : 2ull; }();
             p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
+            {   // longest-remaining-first issue priority for the units in flight when the queue runs dry (gamdp_dev.h)
+                static const bool no_prio = std::getenv("GAMDP_NO_PRIO") != nullptr;
+                const u64 tpw = (u64)kernel_tasks_per_wave(L.kid), units = L.count / tpw;
+                p.prio_R = no_prio ? 0u : (u32)std::max<u64>(1, L.dir_words / (u64)kernel_dir_block_words(L.kid));
+                p.prio_from = units <= 2ull * L.n_slots ? 0u : (u32)(units - L.n_slots);
+            }
             HIPCHK(this, hipEventRecord(events[li].first, stream));
             const int e = launch_align(L.kid, p, L.n_slots, L.dyn_lds, stream);
             if (e != 0) { set_error(std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)e)); return GAMDP_EHIP; }

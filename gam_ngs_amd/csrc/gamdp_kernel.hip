@@ -55,7 +55,7 @@ __shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise
 
 // ---- the whole task -------------------------------------------------------------------------------
 template <int C, int CE, bool HASN>
-__device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane)
+__device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane, const bool lrpt)
 {
     Tk t;
     t.a2 = as_global(dt.a2); t.an = as_global(dt.an); t.b2 = as_global(dt.b2); t.bn = as_global(dt.bn);
@@ -80,11 +80,13 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
     }
     const int X = t.X, w = t.band;
     const int LE = (t.Y - 1) / C;  // lane holding the last band column
+    const int nblk = (X - 1 + LE) / ROWS + 1;
+    t.prio_R = lrpt ? (int)p.prio_R : 0; t.prio_nblk = nblk;
+    if (t.prio_R != 0) set_prio_by_remaining(nblk, t.prio_R);
     BlockState<C> st;
     init_row0<C, HASN, DIRFREE_OK<CE, C, HASN>>(&st, &t, lane);
 
     // ---- phase B: rows 1..X-1 in blocks of 16 row-times ----------------------------------------------------
-    const int nblk = (X - 1 + LE) / ROWS + 1;
     const int64_t iE0 = t.end_a - t.begin_a - w, iE1 = t.end_a - t.begin_a + w;
     auto mode_of = [&](const int blk) {
         const int tau0 = blk * ROWS;
@@ -134,6 +136,7 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
             ++blk;
         }
     }
+    if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);   // end cell + walk: few vector instructions, whoever still fills goes first
     finish_task<C, CE, HASN>(&t, &dt, &p, lane);
 }
 
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align(const Launch
         if (lane == 0) ti = atomicAdd(p.cursor, 1u);
         ti = __builtin_amdgcn_readfirstlane(ti);
         if (ti >= p.n_tasks) break;
-        run_task<C, CE, HASN>(p.tasks[ti], p, slot, lane);
+        run_task<C, CE, HASN>(p.tasks[ti], p, slot, lane, p.prio_R != 0 && ti >= p.prio_from);
     }
 }
 
@@ -168,6 +171,7 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
     t.df_lo = t.df_hi = 0;
+    t.prio_R = t.prio_nblk = 0;
     const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
     t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
     const bool ge = t.end_a >= (int64_t)t.begin_a + t.band;
@@ -338,6 +342,11 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    if (p.prio_R != 0 && qi >= p.prio_from) {
+        ta.prio_R = tb.prio_R = (int)p.prio_R;
+        ta.prio_nblk = tb.prio_nblk = max(pa.nblk, pb.nblk);
+        set_prio_by_remaining(ta.prio_nblk, ta.prio_R);
+    }
     BlockState<C> sta, stb;
     init_row0<C, HASN, true>(&sta, &ta, lane);
     tagged_blocks<C, CE, HASN>(&sta, &ta, pa, 0, hi > lo ? lo : pa.nblk, lane);
@@ -357,6 +366,7 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
 #ifdef GAMDP_EXP_HWID
     const long long exp_t1 = wall_clock64();
 #endif
+    if (ta.prio_R != 0) __builtin_amdgcn_s_setprio(0);
     finish_many<C, CE, HASN, true, 2, 64>(p, 2 * qi, ta, tb, lane, (p.flags & LP_WALK_SIDE_BY_SIDE) != 0);
 #ifdef GAMDP_EXP_HWID
     // placement experiment (results unusable): task A's record carries when the pair started and when its fill ended
@@ -412,11 +422,13 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     }
     const int X = t.X, w = t.band;
     const int LE = (t.Y - 1) / C;
+    const int nblk = (X - 1 + LE) / ROWS + 1;      // of this lane's task
+    const int nblk_max = quad_max(nblk);
+    t.prio_R = (p.prio_R != 0 && qi >= p.prio_from) ? (int)p.prio_R : 0; t.prio_nblk = nblk_max;
+    if (t.prio_R != 0) set_prio_by_remaining(nblk_max, t.prio_R);
     BlockState<C> st;
     init_row0<C, HASN, true, LPT>(&st, &t, lane);
 
-    const int nblk = (X - 1 + LE) / ROWS + 1;      // of this lane's task
-    const int nblk_max = quad_max(nblk);
     const int64_t iE0 = t.end_a - t.begin_a - w, iE1 = t.end_a - t.begin_a + w;
     auto mode_of = [&](const int blk) {             // per lane: the mode its own task needs for this block
         const int tau0 = blk * ROWS;
@@ -461,6 +473,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
             ++blk;
         }
     }
+    if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);
     finish_many<C, CE, HASN, false, QT>(p, 4 * qi, t, t, lane);
 }
 
@@ -507,6 +520,11 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     int lo = (quad_max(max(pa.b0, pb.b0)) + 1 + 3) & ~3, mid = quad_min(min(pa.b1, pb.b1)) & ~3, hi = quad_min(min(pa.b2, pb.b2)) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || quad_or((int)((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE))) lo = mid = hi = 0;
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    if (p.prio_R != 0 && qi >= p.prio_from) {
+        ta.prio_R = tb.prio_R = (int)p.prio_R;
+        ta.prio_nblk = tb.prio_nblk = max(nA, nB);
+        set_prio_by_remaining(ta.prio_nblk, ta.prio_R);
+    }
     BlockState<C> sta, stb;
     init_row0<C, HASN, true, QL>(&sta, &ta, lane);
     quad_tagged_blocks<C, CE, HASN>(&sta, &ta, pa, 0, hi > lo ? lo : nA, lane);
@@ -523,6 +541,7 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
 #ifdef GAMDP_EXP_PHASES
     const long long tf1 = wall_clock64();
 #endif
+    if (uni(ta.prio_R) != 0) __builtin_amdgcn_s_setprio(0);
     finish_many<C, CE, HASN, true, 2 * QT>(p, 8 * qi, ta, tb, lane);
 #ifdef GAMDP_EXP_PHASES
     if (lane == 0) p.results[p.tasks[8 * qi].res_idx].begin_a = (int)(tf1 - tf0);
