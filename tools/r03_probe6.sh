@@ -1,0 +1,15 @@
+# round 3, probe 6: value strips -- headline / short launches / band 150
+mkdir -p gpurun_out/r03_probe6
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --no-proxy"
+run() { name=$1; shift; $B "$@" > gpurun_out/r03_probe6/$name.log 2>&1; python - gpurun_out/r03_probe6/$name.log $name <<'PY'
+import json,sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d=json.loads(l); print("%-22s gcups %.0f kernel_ms %.1f ms_step %.1f kernel %s"%(sys.argv[2], d["value"], d["roofline"]["kernel_ms_per_launch"], d["ms_per_step"], d["roofline"]["kernel"]))
+PY
+}
+run b512_100k
+run b512_12500 --pairs 12500
+run b512_4096 --pairs 4096
+run b150_100k --band 150
+run b512_5k --len 5000 --pairs 200000
