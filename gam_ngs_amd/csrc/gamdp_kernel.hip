@@ -305,7 +305,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
 #endif
     // (with four int32 tasks the side-by-side walk spends as many vector instructions per task as the one-task walk, which
     // keeps its bookkeeping on the scalar unit: measured 6 % slower on 98 304 x 50 kb; eight packed tasks: 4 % faster)
-    if constexpr ((NT == 8 || LPT == 64) && !(PK && !HASN))   // (packed kernels: walk_many on values is not written yet)
+    if constexpr ((NT == 8 || LPT == 64) && !(GAMDP_VALUE_STRIPS && PK && !HASN))   // (the value-strip experiment has no side-by-side walk)
         if (side_by_side && skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane);
 #ifdef GAMDP_EXP_PHASES
     const long long tp2 = wall_clock64();
@@ -318,7 +318,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
         const int lb = (LPT == 64) ? 0 : QL * (s & 3), hs = (LPT == 64) ? s : s >> 2;
         // (packed kernels: finish_walk stops wherever the walk enters the direction-free blocks; walk_values takes it through them)
         while (!finish_walk<C, CE, HASN, LPT, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s])) {
-            if constexpr (PK && !HASN) walk_values<C, CE, LPT>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);
+            if constexpr (GAMDP_VALUE_STRIPS && PK && !HASN) walk_values<C, CE, LPT>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);
         }
     }
 #ifdef GAMDP_EXP_PHASES
@@ -625,6 +625,7 @@ int kernel_ckpt_words(int kid)
 
 int kernel_vimg_words(int kid)
 {
+    if (!GAMDP_VALUE_STRIPS) return 0;
     if (kid == K_P17_CE4) return (int)VImg<17, 64>::WORDS;
     if (kid == K_O19_CE15) return (int)VImg<19, QL>::WORDS;
     return 0;

@@ -20,4 +20,5 @@ avg = lambda f: sum(f(out[k]) for k in range(P)) / P
 calls, mt, wt, it, rf = avg(lambda r: r.n_match), avg(lambda r: r.first_a), avg(lambda r: r.first_b), avg(lambda r: r.last_a), avg(lambda r: r.last_b)
 print("band %d, %d pairs of %d: kernel %.1f ms; per task: %.1f materialise calls, %.1f us in them (%.1f us per call), whole walk %.1f us, "
       "%.0f walk iterations, %.0f direction-cache refills" % (band, P, length, ms, calls, mt / 100.0, mt / 100.0 / max(calls, 1e-9), wt / 100.0, it, rf))
+print("  (packed kernels: 'whole walk' = time inside walk_values incl. materialise_v; iterations / refills are walk_values' own)")
 print("  first tasks: calls", [out[k].n_match for k in range(8)], "iterations", [out[k].last_a for k in range(8)])
