@@ -101,6 +101,98 @@ enum KernelId : int {
     K_COUNT
 };
 
+// ---- the pre-checks of find_alignment on plain numbers (banded_smith_waterman.cc:90-132), shared by the host (every call is
+// validated and sized before it is launched) and the merge-block chain kernel (which derives the next call of a chain on
+// the device).  Returns ST_OK (0) when the call has to run (then *X_out = rows of the band matrix), otherwise the final
+// status the reference's behaviour maps to (1 EMPTY, 2 OUT_OF_RANGE, 3 INVALID = GAMDP_ST_*); *cells_out = x_size * y_size
+// whenever the reference got as far as sizing its matrix.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define GAMDP_HD __host__ __device__
+#else
+#define GAMDP_HD
+#endif
+GAMDP_HD inline int preflight_hd(u64 alen, u64 blen, u64 band, u64 begin_a, u64 end_a, u64 begin_b, u64 end_b, bool fs, bool fe,
+                                 u64* X_out, u64* cells_out)
+{
+    constexpr int64_t MAXGAP = 10;   // FORCE_MAXGAP_LEN, banded_smith_waterman.hpp:37
+    enum { S_OK = 0, S_EMPTY = 1, S_OOR = 2, S_INVALID = 3 };
+    auto mn = [](int64_t x, int64_t y) { return x < y ? x : y; };
+    *X_out = 0;
+    *cells_out = 0;
+    if (end_b < begin_b) return S_EMPTY;                              // :90
+    if (begin_a >= (1ull << 31) - 65536) return S_INVALID;            // beyond any contig this code addresses
+    const int64_t lo = ((int64_t)begin_a - (int64_t)band) > 0 ? ((int64_t)begin_a - (int64_t)band) : 0, hi = (int64_t)begin_a + (int64_t)band;
+    if (begin_b >= blen) {
+        // b.at(begin_b) / a.at(pos) throws in the row-0 loop once a column qualifies (:116-131)
+        bool any;
+        if (!fs) any = lo < (int64_t)alen;                            // some 0 <= pos < |a| in the band
+        else any = (lo <= mn(hi, MAXGAP)) || lo < (int64_t)alen;
+        return any ? S_OOR : S_INVALID;
+    }
+    if (end_b >= blen) end_b = blen - 1;                              // :91
+    u64 X = end_b - begin_b + 1;                                      // :93-95
+    const u64 lim = alen + band - begin_a;                            // unsigned wrap as in the reference
+    if (lim < X) X = lim;
+    if (X > 500000) X = 500000;
+    if (X == 0) return S_INVALID;
+    const u64 Y = 2 * band + 1;
+    *X_out = X;
+    *cells_out = X * Y;
+    if (fs) {  // row 0 touches a.at(pos) for every 0 <= pos <= 10 in the band, even past |a| (:116)
+        const int64_t up = mn(hi, MAXGAP);
+        if (lo <= up && up >= (int64_t)alen) return S_OOR;
+    }
+    if (begin_a > alen + band) {
+        // `lim` wrapped (the reference computes |a| + band - begin_a in unsigned long, :93-95): X is bounded by the b
+        // window alone and EVERY cell has pos >= |a|, so the matrix keeps its zeros and the fill does nothing.  The
+        // outcome follows from the end-cell scan (:174-212) alone: any eligible cell wins with value 0, lies outside a,
+        // and the traceback throws from a.at(pos); no eligible cell -> MyAlignment().  Resolved here: the kernels
+        // never see a window that starts past the padded contig.
+        bool found = false;
+        if (!fe) found = begin_a + (X - 1) - band <= end_a;                      // last row, column 0 has the smallest pos
+        {
+            const bool ge = end_a >= begin_a + band;
+            const int64_t i0 = ge ? (int64_t)(end_a - (begin_a + band)) : 0;
+            const int64_t j0 = ge ? (int64_t)(2 * band) : (int64_t)(2 * band) - (int64_t)(begin_a + band - end_a);
+            if (j0 >= 0 && (u64)i0 < X) {
+                const int64_t kmax = mn((int64_t)X - 1 - i0, j0);  // cells (i0 + k, j0 - k), k = 0..kmax
+                if (!fe) found = true;
+                else if (X >= (u64)MAXGAP + 1 && (u64)(i0 + kmax) >= X - 1 - (u64)MAXGAP) found = true;
+            }
+        }
+        return found ? S_OOR : S_EMPTY;
+    }
+    return S_OK;
+}
+
+// ---- the main chain of a merge block on the device (k_chain, gamdp_kernel.hip) -----------------------------------------
+// One wavefront takes a merge block through alignBlocks' serial chain (PctgBuilder.cc:1617-1708: block k starts where block
+// k-1's last match ended, plus the gap between the blocks) and the orientation retry of findBestAlignment (:1420-1509)
+// without returning to the host: the next window, the pre-checks, is_good(vector) (:1711-1724) are integer arithmetic.  Every
+// find_alignment call leaves its result record in the audit list of its merge block, in call order; the host replays its
+// own state machine over that list (gamdp_l1.cpp), so the decisions are taken twice and compared.
+struct DevBlk { int32_t m_begin, m_end, s_begin, s_end; };   // in chain order (first block of the chain first)
+struct DevMB {
+    const u32 *a2, *an;            // master contig (the `a` sequence of every call of the chain)
+    const u32 *b2, *bn;            // slave contig, forward
+    const u32 *b2rc, *bnrc;        // slave contig, reverse complement
+    u64 mlen, slen;
+    u64 m_start, s_start, s_end;   // region (alignMergeBlock :741-744)
+    u64 align_thr;
+    u32 first_blk, n_blocks;       // its blocks in the DevBlk array
+    u32 audit_first;               // its first record in the audit list (room for 2 * n_blocks)
+    u32 try_rev;                   // orientation of the first attempt
+};
+struct ChainOut { u32 n_dp; u32 state; };   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
+struct ChainParams {
+    const DevMB* mbs; const DevBlk* blks; u32 n_mbs;
+    u32 first_mb;                  // the launch takes merge blocks first_mb .. first_mb + grid - 1
+    u32* cursor;
+    DevResult* audit; ChainOut* out;
+    u32* scratch; u64 slot_words, dir_words; u32 ypad; u32 band;
+};
+int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int
+
 int kernel_cols(int kid);
 int kernel_dir_block_words(int kid);  // words per block (16 row-times) of a task's direction image
 // launches on `stream`; returns hipError_t as int

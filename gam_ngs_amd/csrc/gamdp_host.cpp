@@ -270,6 +270,8 @@ Ctx::~Ctx()
     if (d_results) (void)hipFree(d_results);
     if (d_ops) (void)hipFree(d_ops);
     if (d_cursor) (void)hipFree(d_cursor);
+    if (d_chain) (void)hipFree(d_chain);
+    if (h_chain) (void)hipHostFree(h_chain);
     if (h_tasks) (void)hipHostFree(h_tasks);
     if (h_results) (void)hipHostFree(h_results);
     if (stream) (void)hipStreamDestroy(stream);
@@ -366,52 +368,7 @@ static void sort_by_key_desc(std::vector<u32>& ids, const std::vector<u64>& key)
 int preflight(u64 alen, u64 blen, u64 band, u64 begin_a, u64 end_a, u64 begin_b, u64 end_b, bool fs, bool fe,
               u64* X_out, u64* cells_out)
 {
-    *X_out = 0;
-    *cells_out = 0;
-    if (end_b < begin_b) return GAMDP_ST_EMPTY;                       // :90
-    if (begin_a >= (1ull << 31) - 65536) return GAMDP_ST_INVALID;     // beyond any contig this code addresses
-    const int64_t lo = std::max<int64_t>(0, (int64_t)begin_a - (int64_t)band), hi = (int64_t)begin_a + (int64_t)band;
-    if (begin_b >= blen) {
-        // b.at(begin_b) / a.at(pos) throws in the row-0 loop once a column qualifies (:116-131)
-        bool any;
-        if (!fs) any = lo < (int64_t)alen;                            // some 0 <= pos < |a| in the band
-        else any = (lo <= std::min<int64_t>(hi, FORCE_MAXGAP_)) || lo < (int64_t)alen;
-        return any ? GAMDP_ST_OUT_OF_RANGE : GAMDP_ST_INVALID;
-    }
-    if (end_b >= blen) end_b = blen - 1;                              // :91
-    u64 X = end_b - begin_b + 1;                                      // :93-95
-    const u64 lim = alen + band - begin_a;                            // unsigned wrap as in the reference
-    if (lim < X) X = lim;
-    if (X > 500000) X = 500000;
-    if (X == 0) return GAMDP_ST_INVALID;
-    const u64 Y = 2 * band + 1;
-    *X_out = X;
-    *cells_out = X * Y;
-    if (fs) {  // row 0 touches a.at(pos) for every 0 <= pos <= 10 in the band, even past |a| (:116)
-        const int64_t up = std::min<int64_t>(hi, FORCE_MAXGAP_);
-        if (lo <= up && up >= (int64_t)alen) return GAMDP_ST_OUT_OF_RANGE;
-    }
-    if (begin_a > alen + band) {
-        // `lim` wrapped (the reference computes |a| + band - begin_a in unsigned long, :93-95): X is bounded by the b
-        // window alone and EVERY cell has pos >= |a|, so the matrix keeps its zeros and the fill does nothing.  The
-        // outcome follows from the end-cell scan (:174-212) alone: any eligible cell wins with value 0, lies outside a,
-        // and the traceback throws from a.at(pos); no eligible cell -> MyAlignment().  Resolved here: the kernels
-        // never see a window that starts past the padded contig.
-        bool found = false;
-        if (!fe) found = begin_a + (X - 1) - band <= end_a;                      // last row, column 0 has the smallest pos
-        {
-            const bool ge = end_a >= begin_a + band;
-            const int64_t i0 = ge ? (int64_t)(end_a - (begin_a + band)) : 0;
-            const int64_t j0 = ge ? (int64_t)(2 * band) : (int64_t)(2 * band) - (int64_t)(begin_a + band - end_a);
-            if (j0 >= 0 && (u64)i0 < X) {
-                const int64_t kmax = std::min<int64_t>((int64_t)X - 1 - i0, j0);  // cells (i0 + k, j0 - k), k = 0..kmax
-                if (!fe) found = true;
-                else if (X >= (u64)FORCE_MAXGAP_ + 1 && (u64)(i0 + kmax) >= X - 1 - (u64)FORCE_MAXGAP_) found = true;
-            }
-        }
-        return found ? GAMDP_ST_OUT_OF_RANGE : GAMDP_ST_EMPTY;
-    }
-    return GAMDP_ST_OK;
+    return preflight_hd(alen, blen, band, begin_a, end_a, begin_b, end_b, fs, fe, X_out, cells_out);   // gamdp_dev.h: shared with the chain kernel
 }
 
 // returns GAMDP_ST_OK when the task has to run on the GPU, otherwise its final status
@@ -448,7 +405,7 @@ static int prepare_task(const ITask& it, Prepared& pr)
     return GAMDP_ST_OK;
 }
 
-static void fill_result(const DevResult& r, u64 cells, gamdp_result& o)
+void fill_result(const DevResult& r, u64 cells, gamdp_result& o)
 {
     std::memset(&o, 0, sizeof(o));
     o.status = (uint8_t)(r.flags >> 8);

@@ -118,6 +118,10 @@ struct Ctx {
     std::vector<u64> w_key;
     std::vector<ITask> w_tasks;
 
+    // buffers of the merge-block chain kernel (gamdp_l1.cpp), kept between calls
+    void* d_chain = nullptr; u64 cap_chain = 0;    // device: DevMB[] | DevBlk[] | DevResult audit[] | ChainOut[] | cursor
+    void* h_chain = nullptr; u64 cap_hchain = 0;   // pinned mirror
+
     int align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops);
     int align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops) { return align(tasks.data(), tasks.size(), out, ops); }
     ~Ctx();
@@ -155,6 +159,9 @@ struct Threads {
     void join() { for (auto& t : th) if (t.joinable()) t.join(); }
     ~Threads() { join(); }
 };
+
+// DevResult record + the cell count of its call -> the C ABI's result (gamdp_host.cpp)
+void fill_result(const DevResult& r, u64 cells, gamdp_result& o);
 
 // deterministic longest-processing-time-first partition (gamdp_multi.cpp)
 void partition_lpt(const u64* weights, size_t n, int parts, u32* part_of);

@@ -585,7 +585,127 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align_q(const Laun
     }
 }
 
+// ---- the main chain of a merge block, one wavefront per merge block (structures and rationale: gamdp_dev.h) --------------
+// Band 150 only (gam-merge's live band): the one-task kernel shape k_align<5, 0, HASN> run call after call by the same
+// wavefront.  Everything but the DP itself is wave-uniform integer arithmetic that restates gamdp_l1.cpp's Machine for the
+// MAIN phase (PctgBuilder.cc:1420-1509, 1617-1724); the host replays that machine over the audit list afterwards.
+template <bool HASN>
+__device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slot, const int lane)
+{
+    const DevMB* mb = unip(cp.mbs + mi);
+    const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
+    const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
+    const u64 align_thr = (u64)uni64((int64_t)mb->align_thr);
+    const u32 first_blk = (u32)uni((int)mb->first_blk), n = (u32)uni((int)mb->n_blocks), audit_first = (u32)uni((int)mb->audit_first);
+    const u32 band = cp.band;
+    bool try_rev = uni((int)mb->try_rev) != 0;
+    auto frame_len = [](const int32_t b, const int32_t e) -> int32_t { return e < b ? 0 : e - b + 1; };   // Frame.cc:124-127
+    u32 n_dp = 0, state = 1;
+    for (int attempt = 0;; ) {
+        int64_t cur_ms = (int64_t)m_start;
+        int64_t cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);   // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
+        u64 last_a = 0, last_b = 0, sumlen = 0;
+        bool all_good = true, thrown = false;
+        for (u32 k = 0; k < n; ++k) {
+            const DevBlk* bk = unip(cp.blks + first_blk + k);
+            const int32_t cm_b = uni(bk->m_begin), cm_e = uni(bk->m_end), cs_b = uni(bk->s_begin), cs_e = uni(bk->s_end);
+            const int32_t ml = frame_len(cm_b, cm_e), sl = frame_len(cs_b, cs_e);
+            if (k > 0) {  // :1660-1667
+                const int32_t pm_b = uni(bk[-1].m_begin), pm_e = uni(bk[-1].m_end), ps_b = uni(bk[-1].s_begin), ps_e = uni(bk[-1].s_end);
+                const int32_t mgap = pm_b <= cm_b ? (cm_b - pm_e - 1) : (pm_b - cm_e - 1);
+                const int32_t sgap = ps_b <= cs_b ? (cs_b - ps_e - 1) : (ps_b - cs_e - 1);
+                cur_ms = (int64_t)(last_a + (u64)(int64_t)mgap); if (cur_ms < 0) cur_ms = 0;
+                cur_ss = (int64_t)(last_b + (u64)(int64_t)sgap); if (cur_ss < 0) cur_ss = 0;
+            }
+            const u64 begin_a = (u64)cur_ms, end_a = (u64)(cur_ms + ml - 1), begin_b = (u64)cur_ss, end_b = (u64)(cur_ss + sl - 1);
+            u64 X = 0, cells = 0;
+            const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
+            const u32 idx = audit_first + n_dp;
+#ifdef GAMDP_DIAG
+            if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x1000u | ((u32)st << 16) | (k << 20); cp.out[mi] = o; }   // progress marker (overwritten at the end)
+#endif
+            DevResult r;
+            if (st != 0) {   // settled without a DP, exactly as the host settles it (Ctx::align)
+                r.begin_a = r.begin_b = r.score = 0; r.n_match = r.length = 0;
+                r.first_a = r.first_b = r.last_a = r.last_b = 0;
+                r.flags = (u32)st << 8;
+                if (lane == 0) cp.audit[idx] = r;
+            } else {
+                DevTask dt;
+                dt.a2 = mb->a2; dt.an = mb->an;
+                dt.b2 = try_rev ? mb->b2rc : mb->b2; dt.bn = try_rev ? mb->bnrc : mb->bn;
+                dt.a_base = 0; dt.b_base = 0;
+                dt.end_a = (int64_t)(end_a < (1ull << 40) ? end_a : (1ull << 40));
+                dt.alen = (int32_t)mlen; dt.blen = (int32_t)slen;
+                dt.begin_a = (int32_t)begin_a; dt.begin_b = (int32_t)begin_b;
+                dt.X = (int32_t)X; dt.band = (int32_t)band;
+                dt.flags = 0; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
+                run_task<5, 0, HASN>(dt, p, slot, lane, false);
+#ifdef GAMDP_DIAG
+                if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x2000u | (k << 20); cp.out[mi] = o; }
+#endif
+                // the record lane 0 just wrote: wait until L2 has it, drop this CU's L1 lines, read it back (wave-uniform)
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const DevResult* rp = cp.audit + idx;
+                r.flags = (u32)uni((int)rp->flags); r.n_match = (u32)uni((int)rp->n_match); r.length = (u32)uni((int)rp->length);
+                r.last_a = uni(rp->last_a); r.last_b = uni(rp->last_b);
+            }
+            ++n_dp;
+#ifdef GAMDP_DIAG
+            if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x3000u | (k << 20) | (r.flags & 0xf00u); cp.out[mi] = o; }
+#endif
+            const u32 status = r.flags >> 8;
+            if (status == ST_OUT_OF_RANGE || status == 3u) { thrown = true; break; }   // the reference throws / undefined: the machine stops (finish_bad)
+            if (status == ST_OK) {
+                // homology >= 95 <=> n_match * 100 >= 95 * length (the quotient the host compares is correctly rounded and the
+                // distance of n_match * 100 / length from 95 is either 0 or at least 1 / length: no rounding across 95)
+                if (r.length == 0 || (u64)r.n_match * 100u < 95ull * (u64)r.length) all_good = false;
+                sumlen += r.length;
+                last_a = (u64)(int64_t)r.last_a; last_b = (u64)(int64_t)r.last_b;
+            } else {   // EMPTY: MyAlignment(), homology 0, last match (0, 0)
+                all_good = false;
+                last_a = last_b = 0;
+            }
+        }
+#ifdef GAMDP_DIAG
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x4000u | (all_good ? 1u : 0u) | (thrown ? 2u : 0u) | ((sumlen >= align_thr) ? 4u : 0u); cp.out[mi] = o; }
+#endif
+        if (thrown) { state = 2; break; }
+        if (all_good && sumlen >= align_thr) { state = try_rev ? 0x100u : 0u; break; }   // is_good(vector), :1711-1724
+        if (++attempt == 2) { state = 1; break; }                                          // :1512
+        try_rev = !try_rev;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.out[mi] = o; }
+}
+
+// One workgroup (= one wavefront) per merge block, no work queue: the grid is the list (longest chains first), every workgroup
+// owns the scratch slot of its index.  (A persistent-wavefront version with an atomic cursor hung on the device after the last
+// call of every chain -- its loop exit had been compiled lane-wise; not pursued: a merge-block call has far fewer merge blocks
+// than the scratch arena has room for slots, and the host launches in pieces when it does not.)
+template <bool HASN>
+__global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainParams cp)
+{
+    const int lane = threadIdx.x;
+    const u32 mi = cp.first_mb + blockIdx.x;
+    u32* slot = cp.scratch + (u64)blockIdx.x * cp.slot_words;
+    LaunchParams p;
+    p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
+    p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
+    p.ckpt_off = 0; p.bnd_off = 0; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    run_chain<HASN>(cp, p, mi, slot, lane);
+}
+
 }  // namespace
+
+int launch_chain(const ChainParams& p, bool has_n, unsigned n_slots, void* stream)
+{
+    ChainParams cp = p;
+    void* args[] = {&cp};
+    const void* f = has_n ? (const void*)k_chain<true> : (const void*)k_chain<false>;
+    return (int)hipLaunchKernel(f, dim3(n_slots), dim3(64), args, 0, static_cast<hipStream_t>(stream));
+}
 
 int kernel_cols(int kid)
 {

@@ -371,6 +371,164 @@ void run_cohort(Ctx* c, std::vector<Machine>& M, const std::vector<u32>& ids, st
     }
 }
 
+// ---- the main chains on the device (k_chain, gamdp_dev.h) ------------------------------------------------------------
+// One launch takes every merge block through alignBlocks' chain and the orientation retry; afterwards the host replays its
+// own machines over the result records the device left (so every decision is taken twice: a difference is an internal
+// error, not a wrong answer), and what is left -- the tail alignments, at most two more calls per merge block -- goes
+// through the round loop below.  Band 150 (the only band gam-merge runs) and contigs below 2^31 bases; anything else, and
+// GAMDP_L1_ROUNDS=1, keeps the round loop for the whole call.  Returns 0, or an error code; *launched says whether it ran.
+int run_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const SeqSet* ss, const u32 band, bool* launched, double* kernel_ms)
+{
+    *launched = false;
+    static const bool rounds_only = std::getenv("GAMDP_L1_ROUNDS") != nullptr;
+    if (rounds_only || band != 150) return 0;
+    std::vector<u32> act;
+    for (u32 i = 0; i < (u32)M.size(); i++)
+        if (M[i].phase == Machine::MAIN) act.push_back(i);
+    if (act.empty()) return 0;
+    // longest chains first
+    std::vector<u64> w(act.size(), 0);
+    u32 max_sl = 1;
+    u64 n_blk = 0;
+    bool has_n = false;
+    std::vector<u32> need_rc;
+    for (size_t q = 0; q < act.size(); q++) {
+        const gamdp_mb_in& in = *M[act[q]].in;
+        for (u32 k = 0; k < in.n_blocks; k++) {
+            const int32_t sl = frame_len(in.blocks[k].s_begin, in.blocks[k].s_end);
+            w[q] += (u64)sl;
+            max_sl = std::max<u32>(max_sl, (u32)sl);
+        }
+        n_blk += in.n_blocks;
+        has_n = has_n || ms->has_n[in.m_id] || ss->has_n[in.s_id];
+        need_rc.push_back((u32)in.s_id);
+    }
+    { int rc_ = ss->ensure_rc(need_rc, c); if (rc_) return rc_; }
+    std::vector<u32> order(act.size());
+    for (u32 q = 0; q < order.size(); q++) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return w[x] > w[y]; });
+
+    // one buffer: DevMB[] | DevBlk[] | ChainOut[] | cursor | DevResult audit[]
+    const u64 n_mb = act.size(), n_audit = 2 * n_blk;
+    auto up = [](u64 v) { return (v + 255) & ~255ull; };
+    const u64 off_mb = 0, off_blk = up(off_mb + n_mb * sizeof(DevMB)), off_out = up(off_blk + n_blk * sizeof(DevBlk)),
+              off_cur = up(off_out + n_mb * sizeof(ChainOut)), off_aud = up(off_cur + 256), total = up(off_aud + n_audit * sizeof(DevResult));
+    if (total > c->cap_chain) {
+        if (c->d_chain) (void)hipFree(c->d_chain);
+        c->d_chain = nullptr; c->cap_chain = 0;
+        if (hipMalloc(&c->d_chain, total + total / 4) != hipSuccess) { c->set_error("hipMalloc of the chain buffers failed"); return GAMDP_ENOMEM; }
+        c->cap_chain = total + total / 4;
+    }
+    if (total > c->cap_hchain) {
+        if (c->h_chain) (void)hipHostFree(c->h_chain);
+        c->h_chain = nullptr; c->cap_hchain = 0;
+        if (hipHostMalloc(&c->h_chain, total + total / 4) != hipSuccess) { c->set_error("hipHostMalloc of the chain buffers failed"); return GAMDP_ENOMEM; }
+        c->cap_hchain = total + total / 4;
+    }
+    uint8_t* const h = (uint8_t*)c->h_chain;
+    uint8_t* const d = (uint8_t*)c->d_chain;
+    DevMB* hmb = (DevMB*)(h + off_mb);
+    DevBlk* hbk = (DevBlk*)(h + off_blk);
+    std::memset(h + off_cur, 0, 256);
+    u32 blk_at = 0;
+    for (size_t q = 0; q < n_mb; q++) {
+        const Machine& m = M[act[order[q]]];
+        const gamdp_mb_in& in = *m.in;
+        DevMB& x = hmb[q];
+        x.a2 = ms->fwd[in.m_id].p2; x.an = ms->fwd[in.m_id].pn;
+        x.b2 = ss->fwd[in.s_id].p2; x.bn = ss->fwd[in.s_id].pn;
+        x.b2rc = ss->rc[in.s_id].p2; x.bnrc = ss->rc[in.s_id].pn;
+        x.mlen = m.mlen; x.slen = m.slen;
+        x.m_start = m.m_start; x.s_start = m.s_start; x.s_end = m.s_end;
+        x.align_thr = m.align_thr;
+        x.first_blk = blk_at; x.n_blocks = in.n_blocks; x.audit_first = 2 * blk_at;
+        x.try_rev = m.try_rev ? 1u : 0u;
+        for (u32 k = 0; k < in.n_blocks; k++) {
+            const gamdp_block& b = m.blk(k);
+            hbk[blk_at + k] = DevBlk{b.m_begin, b.m_end, b.s_begin, b.s_end};
+        }
+        blk_at += in.n_blocks;
+    }
+    // scratch: one slot per resident wavefront, sized for the longest call any chain can make (x_size <= its slave frame)
+    const u64 Y = 2ull * band + 1, LE = (Y - 1) / 5, nblk = ((u64)max_sl - 1 + LE) / 16 + 1;
+    const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
+    const u32 ypad = (u32)(((2 * band + 2 + 63) / 64) * 64);
+    const u64 slotw = dirw + 4ull * ypad;
+    if (c->arena_budget() == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
+    const u64 fit = c->arena_call() / (slotw * sizeof(u32));
+    if (fit == 0) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
+    const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // workgroups per launch: each owns a slot
+    const u64 need_scratch = slotw * n_slots;
+    if (need_scratch > c->cap_scratch) {
+        if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->cap_scratch = 0; }
+        if (hipMalloc(&c->d_scratch, need_scratch * sizeof(u32)) != hipSuccess) { c->d_scratch = nullptr; c->set_error("hipMalloc of scratch arena failed"); return GAMDP_ENOMEM; }
+        c->cap_scratch = need_scratch;
+    }
+    ChainParams cp;
+    cp.mbs = (const DevMB*)(d + off_mb); cp.blks = (const DevBlk*)(d + off_blk); cp.n_mbs = (u32)n_mb;
+    cp.cursor = (u32*)(d + off_cur); cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
+    cp.scratch = c->d_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
+    if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (int)has_n);
+    bool ok = hipMemcpyAsync(d, h, off_aud, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && hipEventRecord(e0, c->stream) == hipSuccess;
+    for (u64 first = 0; ok && first < n_mb; first += n_slots) {   // (one launch unless the arena holds fewer slots than there are merge blocks)
+        cp.first_mb = (u32)first;
+        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)std::min<u64>(n_slots, n_mb - first), c->stream) == 0;
+    }
+    ok = ok && hipEventRecord(e1, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h + off_out, d + off_out, total - off_out, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    if (ok && diag().timing && diag().build) {
+        // diagnostics build: a watchdog instead of a blind wait -- after 5 s dump the progress markers of the chains and give up
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+                hipStream_t s2; (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+                std::vector<ChainOut> o(n_mb);
+                (void)hipMemcpyAsync(o.data(), d + off_out, n_mb * sizeof(ChainOut), hipMemcpyDeviceToHost, s2);
+                (void)hipStreamSynchronize(s2);
+                for (size_t q = 0; q < n_mb; q++) std::fprintf(stderr, "gamdp chain watchdog: mb %zu n_blocks %u: n_dp %u state 0x%x\n", q, hmb[q].n_blocks, o[q].n_dp, o[q].state);
+                std::fflush(stderr);
+                std::_Exit(3);
+            }
+        }
+    }
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+    float ms_k = 0;
+    if (ok) (void)hipEventElapsedTime(&ms_k, e0, e1);
+    if (diag().timing) std::fprintf(stderr, "gamdp chain: kernel done ok=%d %.3f ms\n", (int)ok, ms_k);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (!ok) { c->set_error(std::string("chain kernel: ") + hipGetErrorString(hipGetLastError())); return GAMDP_EHIP; }
+    *kernel_ms = ms_k;
+    c->kernel_ms += ms_k; c->kernel_launches++;
+    // replay: the host's machines over the device's records
+    const ChainOut* hout = (const ChainOut*)(h + off_out);
+    const DevResult* haud = (const DevResult*)(h + off_aud);
+    std::unordered_map<u32, std::vector<uint8_t>> no_cache;
+    std::mutex no_mu;
+    for (size_t q = 0; q < n_mb; q++) {
+        Machine& m = M[act[order[q]]];
+        const DevMB& x = hmb[q];
+        u32 used = 0;
+        while (m.phase == Machine::MAIN) {
+            if (used >= hout[q].n_dp) { c->set_error("internal: the device's chain of merge block " + std::to_string(act[order[q]]) + " is shorter than the host's"); return GAMDP_EHIP; }
+            ITask t;
+            m.pending(t, no_cache, no_mu);
+            u64 X = 0, cells = 0;
+            (void)preflight(m.mlen, m.slen, band, t.begin_a, t.end_a, t.begin_b, t.end_b, false, false, &X, &cells);
+            gamdp_result r;
+            fill_result(haud[x.audit_first + used], cells, r);
+            m.feed(r);
+            used++;
+        }
+        if (used != hout[q].n_dp) { c->set_error("internal: the device's chain of merge block " + std::to_string(act[order[q]]) + " is longer than the host's"); return GAMDP_EHIP; }
+    }
+    if (diag().timing) std::fprintf(stderr, "gamdp chain: replay done\n");
+    *launched = true;
+    return 0;
+}
+
 }  // namespace
 }  // namespace gamdp
 
@@ -402,6 +560,14 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         m.init();
         for (u32 k = 0; k < in[i].n_blocks && in[i].blocks; k++)
             weight[i] += (u64)frame_len(in[i].blocks[k].s_begin, in[i].blocks[k].s_end) * (2ull * band + 1);
+    }
+    const double k0_ms = c->kernel_ms; const u64 k0_n = c->kernel_launches;
+    // Main chains in one launch on the device; what remains for the round loop below are the tail alignments
+    bool chained = false;
+    double chain_ms = 0;
+    {
+        const int rc_chain = run_main_chains(c, M, ms, ss, band, &chained, &chain_ms);
+        if (rc_chain) return rc_chain;
     }
     // Cohorts: host threads, each with its own context (stream, staging buffers, scratch arena) on this device; the merge
     // blocks are dealt by predicted cells (LPT), so the cohorts' chains have similar depth.  A round lasts as long as its
@@ -444,7 +610,6 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     std::vector<CohortStats> cst((size_t)K);
     std::unordered_map<u32, std::vector<uint8_t>> rc_cache;
     std::mutex rc_mu;
-    const double k0_ms = c->kernel_ms; const u64 k0_n = c->kernel_launches;
     auto body = [&](int k) noexcept {
         Ctx* cc = k == 0 ? c : c->helpers[(size_t)k - 1];
         if (k > 0) { cc->kernel_ms = 0; cc->kernel_launches = 0; cc->ref_event = c->ref_event; }
@@ -472,7 +637,7 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     for (size_t i = 0; i < n; i++) { S.dp_calls += out[i].n_dp; S.cells += out[i].cells; }
     std::vector<std::pair<float, float>> all;
     for (int k = 0; k < K; k++) {
-        S.rounds = std::max<uint32_t>(S.rounds, (uint32_t)cst[(size_t)k].rounds);
+        S.rounds = std::max<uint32_t>(S.rounds, (uint32_t)cst[(size_t)k].rounds + (chained ? 1u : 0u));
         S.host_pending_ms += cst[(size_t)k].pending_ms; S.host_feed_ms += cst[(size_t)k].feed_ms;
         all.insert(all.end(), intervals[(size_t)k].begin(), intervals[(size_t)k].end());
     }
@@ -486,6 +651,7 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         else { S.gpu_busy_ms += cur_hi - cur_lo; cur_lo = iv.first; cur_hi = iv.second; }
     }
     if (cur_hi >= cur_lo) S.gpu_busy_ms += cur_hi - cur_lo;
+    S.gpu_busy_ms += chain_ms;   // (the chain launch runs before the round loop's reference event)
     S.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (gamdp::diag().timing)
         std::fprintf(stderr, "gamdp_align_merge_blocks: %zu merge blocks, %d cohorts, %u rounds, %u launches: wall %.2f ms, GPU busy %.2f ms (kernels %.2f ms), pending %.2f ms, feed %.2f ms\n",
