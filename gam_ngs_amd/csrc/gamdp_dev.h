@@ -181,6 +181,7 @@ struct DevMB {
     u64 align_thr;
     u32 first_blk, n_blocks;       // its blocks in the DevBlk array
     u32 audit_first;               // its first record in the audit list (room for 2 * n_blocks)
+    u32 rows;                      // sum of its slave frames: the rows one pass of the chain fills
     u32 try_rev;                   // orientation of the first attempt
 };
 struct ChainOut { u32 n_dp; u32 state; };   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
@@ -190,6 +191,7 @@ struct ChainParams {
     u32* cursor;
     DevResult* audit; ChainOut* out;
     u32* scratch; u64 slot_words, dir_words; u32 ypad; u32 band;
+    u32 max_rows;                  // the largest DevMB::rows of the call: chains with many rows left go first (set_prio_by_remaining)
 };
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int
 

@@ -606,6 +606,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         int64_t cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);   // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
         u64 last_a = 0, last_b = 0, sumlen = 0;
         bool all_good = true, thrown = false;
+        int rows_left = uni((int)mb->rows);
         for (u32 k = 0; k < n; ++k) {
             const DevBlk* bk = unip(cp.blks + first_blk + k);
             const int32_t cm_b = uni(bk->m_begin), cm_e = uni(bk->m_end), cs_b = uni(bk->s_begin), cs_e = uni(bk->s_end);
@@ -618,6 +619,9 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
                 cur_ss = (int64_t)(last_b + (u64)(int64_t)sgap); if (cur_ss < 0) cur_ss = 0;
             }
             const u64 begin_a = (u64)cur_ms, end_a = (u64)(cur_ms + ml - 1), begin_b = (u64)cur_ss, end_b = (u64)(cur_ss + sl - 1);
+            // the call ends when its longest chain does: wavefronts that share a SIMD yield to the one with the most rows left
+            set_prio_by_remaining(rows_left, (int)cp.max_rows);
+            rows_left -= sl;
             u64 X = 0, cells = 0;
             const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
             const u32 idx = audit_first + n_dp;

@@ -442,6 +442,7 @@ int run_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const Seq
         x.m_start = m.m_start; x.s_start = m.s_start; x.s_end = m.s_end;
         x.align_thr = m.align_thr;
         x.first_blk = blk_at; x.n_blocks = in.n_blocks; x.audit_first = 2 * blk_at;
+        x.rows = (u32)std::min<u64>(w[order[q]], 0x7fffffffu);
         x.try_rev = m.try_rev ? 1u : 0u;
         for (u32 k = 0; k < in.n_blocks; k++) {
             const gamdp_block& b = m.blk(k);
@@ -468,6 +469,7 @@ int run_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const Seq
     cp.mbs = (const DevMB*)(d + off_mb); cp.blks = (const DevBlk*)(d + off_blk); cp.n_mbs = (u32)n_mb;
     cp.cursor = (u32*)(d + off_cur); cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
     cp.scratch = c->d_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
+    cp.max_rows = (u32)std::min<u64>(std::max<u64>(1, w[order[0]]), 0x7fffffffu);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (int)has_n);
@@ -572,14 +574,17 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     // Cohorts: host threads, each with its own context (stream, staging buffers, scratch arena) on this device; the merge
     // blocks are dealt by predicted cells (LPT), so the cohorts' chains have similar depth.  A round lasts as long as its
     // longest call, so smaller cohorts mean shorter rounds that overlap on the (nearly empty) GPU -- up to a point: 4 cohorts
-    // of >= 48 merge blocks, 8 from ~1 500 merge blocks on (measured on the GAGE-shaped workloads: 192 merge blocks 12.5 /
-    // 11.5 / 8.8 / 13.1 ms with 1 / 2 / 4 / 8 cohorts, 1 967 merge blocks 103 / 77 / 60 / 54 / 63 ms with 1 / 2 / 4 / 8 / 12).
+    // of >= 48 merge blocks, up to 16 from ~1 500 merge blocks on (measured on the GAGE-shaped workloads when every call went
+    // through this loop: 192 merge blocks 12.5 / 11.5 / 8.8 / 13.1 ms with 1 / 2 / 4 / 8 cohorts, 1 967 merge blocks 103 / 77 /
+    // 60 / 54 / 63 ms with 1 / 2 / 4 / 8 / 12; with the main chains on the device only the tails are left, two rounds bound by
+    // findHits on the host: 192 merge blocks 7.4 / 7.2 / 7.0 / 7.1 ms with 1 / 2 / 4 / 8, 1 967: 56 / 46 / 38 / 37 ms with
+    // 2 / 4 / 8 / 16).
     // GAMDP_L1_COHORTS=k (<= 16) and GAMDP_L1_COHORT_MIN=m set the cap and the floor by hand.  Results do not depend on the
     // split: every machine only sees its own results.
     static const int forced_cohorts = [] { const char* e = std::getenv("GAMDP_L1_COHORTS"); return e ? std::min(16, std::max(1, std::atoi(e))) : 0; }();
     static const size_t cohort_min = [] { const char* e = std::getenv("GAMDP_L1_COHORT_MIN"); const long v = e ? std::atol(e) : 48; return (size_t)std::max(1L, v); }();
     const int K = forced_cohorts ? (int)std::max<size_t>(1, std::min<size_t>((size_t)forced_cohorts, n / cohort_min))
-                                 : (int)std::max<size_t>(1, std::max(std::min<size_t>(4, n / cohort_min), std::min<size_t>(8, n / (4 * cohort_min))));
+                                 : (int)std::max<size_t>(1, std::max(std::min<size_t>(4, n / cohort_min), std::min<size_t>(16, n / (4 * cohort_min))));
     while ((int)c->helpers.size() < K - 1) {
         Ctx* h = new (std::nothrow) Ctx();
         if (!h || h->init(c->device) != 0) { c->set_error("helper context: " + (h ? h->err : std::string("out of memory"))); delete h; return GAMDP_ENODEV; }
