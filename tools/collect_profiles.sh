@@ -2,7 +2,8 @@
 # Collects the rocprofv3 evidence behind bench.py's numbers on the GPU box (run from the repo root):
 #   tools/collect_profiles.sh <tag> [extra bench.py args]     e.g.  tools/collect_profiles.sh r02
 #                                                                    tools/collect_profiles.sh r02_band150 --band 150
-# Pass 1: --kernel-trace --stats of the bench.py run (default workload: 4 launches of the full 100 000-pair set).
+# Pass 1: --kernel-trace --stats of the bench.py run (default workload: 4 launches of the full 100 000-pair set; --no-proxy: the
+# strong-scaling proxies launch the same kernel on other batch sizes and would be averaged into its statistics).
 # Passes 2..6: PMC counters, one set per pass, kernel-trace/stats only (never combined with API traces), each on
 # a single launch (--steps 1 --warmup 0).  Everything lands under gpurun_out/<tag>_*; tools/summarise_profiles.py
 # turns it into the files committed under profiles/.  The commit is recorded next to the data (gpurun_out/<tag>_commit)
@@ -14,13 +15,13 @@ OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ -z "$EXTRA" ]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-proxy > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
 else
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-l1 --no-band150 --no-cpu-baseline $EXTRA > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-l1 --no-band150 --no-proxy --no-cpu-baseline $EXTRA > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
 fi
 pmc() {  # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-l1 --no-band150 $EXTRA > $OUT/${TAG}_$name.log 2>&1
+    rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-l1 --no-band150 --no-proxy $EXTRA > $OUT/${TAG}_$name.log 2>&1
 }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
