@@ -192,6 +192,10 @@ struct ChainParams {
     DevResult* audit; ChainOut* out;
     u32* scratch; u64 slot_words, dir_words; u32 ypad; u32 band;
     u32 max_rows;                  // the largest DevMB::rows of the call: chains with many rows left go first (set_prio_by_remaining)
+    // the host's view while the launch runs (pinned, coherent host memory, device pointers): a chain that ends copies its
+    // records and its ChainOut there and then raises its flag (done[mi] = epoch, system-scope release), so the host takes a
+    // merge block on (replay, tail alignments) while longer chains are still going
+    DevResult* host_audit; ChainOut* host_out; u32* host_done; u32 epoch;
 };
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int
 

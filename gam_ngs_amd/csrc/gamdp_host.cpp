@@ -263,6 +263,7 @@ Ctx::~Ctx()
 {
     for (Ctx* h : helpers) delete h;
     if (device >= 0) (void)hipSetDevice(device);
+    flush_frees();
     if (ref_event) (void)hipEventDestroy(ref_event);
     for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (d_scratch) (void)hipFree(d_scratch);
@@ -272,6 +273,9 @@ Ctx::~Ctx()
     if (d_cursor) (void)hipFree(d_cursor);
     if (d_chain) (void)hipFree(d_chain);
     if (h_chain) (void)hipHostFree(h_chain);
+    if (h_mirror) (void)hipHostFree(h_mirror);
+    if (d_chain_scratch) (void)hipFree(d_chain_scratch);
+    if (chain_stream) (void)hipStreamDestroy(chain_stream);
     if (h_tasks) (void)hipHostFree(h_tasks);
     if (h_results) (void)hipHostFree(h_results);
     if (stream) (void)hipStreamDestroy(stream);
@@ -282,7 +286,7 @@ u64 Ctx::arena_budget()
     if (arena_limit == 0) {
         size_t fr = 0, tot = 0;
         if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-        arena_limit = (u64)((double)(fr + cap_scratch * sizeof(u32)) * 0.75);
+        arena_limit = (u64)((double)(fr + (cap_scratch + cap_chain_scratch) * sizeof(u32)) * 0.75);
     }
     return arena_limit;
 }
@@ -300,7 +304,7 @@ template <class T>
 static int grow(Ctx* ctx, T*& ptr, u64& cap, u64 need)
 {
     if (need <= cap) return 0;
-    if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    if (ptr) { ctx->free_dev(ptr); ptr = nullptr; cap = 0; }
     u64 want = need + need / 4;
     if (hipMalloc(&ptr, want * sizeof(T)) != hipSuccess) {
         if (hipMalloc(&ptr, need * sizeof(T)) != hipSuccess) {
@@ -634,8 +638,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     if (rc_) return rc_;
     // pinned staging for the task upload and the result download (pageable copies cost ~20 ms per 60 k tasks)
     if (std::max<u64>(n_host_tasks, n) + 1 > cap_pinned) {
-        if (h_tasks) (void)hipHostFree(h_tasks);
-        if (h_results) (void)hipHostFree(h_results);
+        free_host(h_tasks);
+        free_host(h_results);
         h_tasks = nullptr; h_results = nullptr; cap_pinned = 0;
         const u64 base = std::max<u64>(n_host_tasks, n), want = base + base / 4 + 256;
         if (hipHostMalloc(&h_tasks, want * sizeof(DevTask)) != hipSuccess ||
@@ -655,15 +659,18 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         u64 need_scratch = 0;
         for (auto& L : launches) need_scratch = std::max(need_scratch, L.slot_words * L.n_slots);
         if (need_scratch > cap_scratch) {
-            if (d_scratch) { (void)hipFree(d_scratch); d_scratch = nullptr; cap_scratch = 0; }
+            if (d_scratch) { free_dev(d_scratch); d_scratch = nullptr; cap_scratch = 0; }
             if (hipMalloc(&d_scratch, need_scratch * sizeof(u32)) != hipSuccess) {
                 // a call on this context alone after calls that shared the device: its idle helper contexts may still
                 // hold their shares of the budget
                 d_scratch = nullptr;
                 (void)hipGetLastError();
-                if (arena_div == 1)
+                flush_frees();   // (buffers kept back while a chain launch runs: now they have to go, whatever the wait)
+                if (arena_div == 1) {
                     for (Ctx* h : helpers)
                         if (h->d_scratch) { (void)hipFree(h->d_scratch); h->d_scratch = nullptr; h->cap_scratch = 0; }
+                    if (d_chain_scratch) { (void)hipFree(d_chain_scratch); d_chain_scratch = nullptr; cap_chain_scratch = 0; }   // (idle: merge-block calls are synchronous)
+                }
                 if (hipMalloc(&d_scratch, need_scratch * sizeof(u32)) != hipSuccess) {
                     d_scratch = nullptr;
                     set_error("hipMalloc of scratch arena (" + std::to_string(need_scratch * sizeof(u32)) + " bytes) failed");
@@ -674,7 +681,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         }
         if (launches.size() > 64) {
             // cursors: one u32 per launch
-            if (d_cursor) (void)hipFree(d_cursor);
+            free_dev(d_cursor);
             d_cursor = nullptr;
             HIPCHK(this, hipMalloc(&d_cursor, launches.size() * sizeof(u32)));
         }

@@ -120,7 +120,25 @@ struct Ctx {
 
     // buffers of the merge-block chain kernel (gamdp_l1.cpp), kept between calls
     void* d_chain = nullptr; u64 cap_chain = 0;    // device: DevMB[] | DevBlk[] | DevResult audit[] | ChainOut[] | cursor
-    void* h_chain = nullptr; u64 cap_hchain = 0;   // pinned mirror
+    void* h_chain = nullptr; u64 cap_hchain = 0;   // pinned: what is uploaded (DevMB[] | DevBlk[])
+    // the chain launch runs beside the round loop's launches: own stream, own scratch slots, and a pinned coherent mirror
+    // (ChainOut[] | done flags | DevResult audit[]) the chains write when they end
+    hipStream_t chain_stream = nullptr;
+    // hipFree / hipHostFree wait for the whole device; while the chain launch runs, a round loop that regrows a buffer keeps
+    // the old one until the call is over (flush_frees) instead of waiting for the launch to end
+    bool defer_frees = false;
+    std::vector<void*> deferred_dev, deferred_host;
+    void free_dev(void* p) { if (!p) return; if (defer_frees) deferred_dev.push_back(p); else (void)hipFree(p); }
+    void free_host(void* p) { if (!p) return; if (defer_frees) deferred_host.push_back(p); else (void)hipHostFree(p); }
+    void flush_frees()
+    {
+        for (void* p : deferred_dev) (void)hipFree(p);
+        for (void* p : deferred_host) (void)hipHostFree(p);
+        deferred_dev.clear(); deferred_host.clear();
+    }
+    u32* d_chain_scratch = nullptr; u64 cap_chain_scratch = 0;   // u32 words
+    void* h_mirror = nullptr; u64 cap_mirror = 0;
+    u32 chain_epoch = 0;
 
     int align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops);
     int align(const std::vector<ITask>& tasks, gamdp_result* out, const gamdp_ops* ops) { return align(tasks.data(), tasks.size(), out, ops); }

@@ -682,6 +682,18 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
     }
     __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.out[mi] = o; }
+    // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        const u32* src = reinterpret_cast<const u32*>(cp.audit + audit_first);
+        u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
+        const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
+        for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.host_out[mi] = o; }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
+    if (lane == 0) __hip_atomic_store(cp.host_done + mi, cp.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One workgroup (= one wavefront) per merge block, no work queue: the grid is the list (longest chains first), every workgroup

@@ -12,6 +12,7 @@
 // round collects the next pending DP call of every unfinished merge block into ONE gamdp L0 batch on
 // the GPU, feeds the results back and advances the machines.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -254,6 +255,15 @@ struct Machine {
     }
     static bool good_one(const gamdp_result& r, u64 min_len) { return r.homology >= MIN_HOMOLOGY && r.length >= min_len; }
 
+    // LEFT phase only: will the right tail be aligned once the left one is fed?  (It depends on the main chain alone -- the
+    // two tail alignments of findBestAlignment, :1535-1611, do not use each other's result -- so the round loop issues both in
+    // one round; they are fed left first, as the reference computes them.)
+    bool right_follows_left() const
+    {
+        if (!(umin(i2, j2) >= thr)) return false;
+        return !((i2 < j2 && slen <= eb + 1) || (!(i2 < j2) && mlen <= ea + 1));   // (else chop_borders throws: enter_right_or_finalize)
+    }
+
     void enter_right_or_finalize()
     {
         if (umin(i2, j2) >= thr) {
@@ -337,49 +347,78 @@ using namespace gamdp;
 namespace gamdp {
 namespace {
 
-struct CohortStats { int rounds = 0; double pending_ms = 0, align_ms = 0, feed_ms = 0; int rc = 0; };
-
-// The round loop over one cohort of merge blocks on one context (= one host thread + one stream): every round collects
-// the next pending find_alignment call of each unfinished machine into ONE L0 batch, feeds the results back and
-// advances the machines.  Cohorts run concurrently: while one waits for its kernel, another builds pending calls
-// (findHits over contig tails, descriptor preparation) or feeds results -- host work hides behind GPU work.
-void run_cohort(Ctx* c, std::vector<Machine>& M, const std::vector<u32>& ids, std::unordered_map<u32, std::vector<uint8_t>>& rc_cache,
-                std::mutex& rc_mu, CohortStats& st)
-{
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto msec = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    std::vector<ITask> tasks;
-    std::vector<u32> owner;
-    std::vector<gamdp_result> res;
-    for (;;) {
-        const auto t0 = now();
-        owner.clear();
-        for (u32 i : ids)
-            if (M[i].phase != Machine::DONE) owner.push_back(i);
-        if (owner.empty()) break;
-        tasks.assign(owner.size(), ITask{});
-        for (size_t q = 0; q < owner.size(); q++) M[owner[q]].pending(tasks[q], rc_cache, rc_mu);
-        const auto t1 = now();
-        res.assign(tasks.size(), gamdp_result{});
-        st.rc = c->align(tasks, res.data(), nullptr);
-        if (st.rc) return;
-        const auto t2 = now();
-        for (size_t q = 0; q < tasks.size(); q++) M[owner[q]].feed(res[q]);
-        const auto t3 = now();
-        st.pending_ms += msec(t0, t1); st.align_ms += msec(t1, t2); st.feed_ms += msec(t2, t3);
-        st.rounds++;
-    }
-}
-
 // ---- the main chains on the device (k_chain, gamdp_dev.h) ------------------------------------------------------------
-// One launch takes every merge block through alignBlocks' chain and the orientation retry; afterwards the host replays its
-// own machines over the result records the device left (so every decision is taken twice: a difference is an internal
-// error, not a wrong answer), and what is left -- the tail alignments, at most two more calls per merge block -- goes
-// through the round loop below.  Band 150 (the only band gam-merge runs) and contigs below 2^31 bases; anything else, and
-// GAMDP_L1_ROUNDS=1, keeps the round loop for the whole call.  Returns 0, or an error code; *launched says whether it ran.
-int run_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const SeqSet* ss, const u32 band, bool* launched, double* kernel_ms)
+// One launch takes every merge block through alignBlocks' chain and the orientation retry.  It runs on its own stream beside
+// the round loop: a chain that ends copies its result records into a pinned mirror and raises a flag; the cohort that owns the
+// merge block then replays its own machine over those records (so every decision is taken twice: a difference is an internal
+// error, not a wrong answer) and sends what is left -- the tail alignments, at most two more calls -- through its next round,
+// while longer chains are still running.  Band 150 (the only band gam-merge runs); anything else, and GAMDP_L1_ROUNDS=1, keeps
+// the round loop for the whole call.
+struct ChainRun {
+    bool launched = false;
+    size_t n_mb = 0;
+    u32 band = 0;
+    std::vector<u32> q_of;     // machine -> its index in the launch (~0u: not part of it)
+    const DevMB* hmb = nullptr;
+    const ChainOut* hout = nullptr;
+    const DevResult* haud = nullptr;
+    const volatile u32* done = nullptr;
+    u32 epoch = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const ChainOut* dout = nullptr;   // device copy of the ChainOut list (progress markers in the diagnostics build)
+    std::chrono::steady_clock::time_point t_launch;
+
+    ChainRun() = default;
+    ChainRun(const ChainRun&) = delete;
+    ChainRun& operator=(const ChainRun&) = delete;
+    ~ChainRun()
+    {   // (only on a path that skipped finish(): an exception between the launch and the join)
+        if (!launched) return;
+        (void)hipStreamSynchronize(stream);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+
+    bool ended(u32 q) const
+    {
+        if (done[q] != epoch) return false;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return true;
+    }
+    // waits for the launch (all paths out of the call, errors included: its buffers belong to the context)
+    int finish(Ctx* c, float* from_ref_ms, float* ms)
+    {
+        if (!launched) return 0;
+        launched = false;
+        bool ok = hipStreamSynchronize(stream) == hipSuccess;
+        float k = 0, f = 0;
+        if (ok) ok = hipEventElapsedTime(&k, e0, e1) == hipSuccess && hipEventElapsedTime(&f, c->ref_event, e0) == hipSuccess;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (!ok) { c->set_error(std::string("chain kernel: ") + hipGetErrorString(hipGetLastError())); return GAMDP_EHIP; }
+        *ms = k; *from_ref_ms = f;
+        c->kernel_ms += k; c->kernel_launches++;
+        if (diag().timing) std::fprintf(stderr, "gamdp chain: kernel %.3f ms, launched %.3f ms after the call began\n", k, f);
+        return 0;
+    }
+    // diagnostics build: the progress markers of the chains
+    void dump(FILE* f) const
+    {
+        hipStream_t s2;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return;
+        std::vector<ChainOut> o(n_mb);
+        (void)hipMemcpyAsync(o.data(), dout, n_mb * sizeof(ChainOut), hipMemcpyDeviceToHost, s2);
+        (void)hipStreamSynchronize(s2);
+        for (size_t q = 0; q < n_mb; q++) std::fprintf(f, "gamdp chain watchdog: mb %zu n_blocks %u: n_dp %u state 0x%x flag %u\n", q, hmb[q].n_blocks, o[q].n_dp, o[q].state, (unsigned)(done[q] == epoch));
+        std::fflush(f);
+        (void)hipStreamDestroy(s2);
+    }
+};
+
+// Starts the launch (asynchronous).  `arena` = bytes its scratch slots may take.  Returns 0 (run.launched says whether there is
+// one: not for other bands, GAMDP_L1_ROUNDS=1, no merge block with a chain, or a frame too long for the arena) or an error code.
+int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const SeqSet* ss, const u32 band, const u64 arena, ChainRun& run)
 {
-    *launched = false;
+    run.launched = false;
     static const bool rounds_only = std::getenv("GAMDP_L1_ROUNDS") != nullptr;
     if (rounds_only || band != 150) return 0;
     std::vector<u32> act;
@@ -408,32 +447,58 @@ int run_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const Seq
     for (u32 q = 0; q < order.size(); q++) order[q] = q;
     std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return w[x] > w[y]; });
 
-    // one buffer: DevMB[] | DevBlk[] | ChainOut[] | cursor | DevResult audit[]
+    // device: DevMB[] | DevBlk[] | ChainOut[] | DevResult audit[]      (the first two uploaded from h_chain)
+    // mirror: ChainOut[] | done flags | DevResult audit[]               (pinned, coherent; written by the chains as they end)
     const u64 n_mb = act.size(), n_audit = 2 * n_blk;
     auto up = [](u64 v) { return (v + 255) & ~255ull; };
     const u64 off_mb = 0, off_blk = up(off_mb + n_mb * sizeof(DevMB)), off_out = up(off_blk + n_blk * sizeof(DevBlk)),
-              off_cur = up(off_out + n_mb * sizeof(ChainOut)), off_aud = up(off_cur + 256), total = up(off_aud + n_audit * sizeof(DevResult));
+              off_aud = up(off_out + n_mb * sizeof(ChainOut)), total = up(off_aud + n_audit * sizeof(DevResult));
+    const u64 mo_out = 0, mo_done = up(mo_out + n_mb * sizeof(ChainOut)), mo_aud = up(mo_done + n_mb * sizeof(u32)), mtotal = up(mo_aud + n_audit * sizeof(DevResult));
     if (total > c->cap_chain) {
         if (c->d_chain) (void)hipFree(c->d_chain);
         c->d_chain = nullptr; c->cap_chain = 0;
         if (hipMalloc(&c->d_chain, total + total / 4) != hipSuccess) { c->set_error("hipMalloc of the chain buffers failed"); return GAMDP_ENOMEM; }
         c->cap_chain = total + total / 4;
     }
-    if (total > c->cap_hchain) {
+    if (off_out > c->cap_hchain) {
         if (c->h_chain) (void)hipHostFree(c->h_chain);
         c->h_chain = nullptr; c->cap_hchain = 0;
-        if (hipHostMalloc(&c->h_chain, total + total / 4) != hipSuccess) { c->set_error("hipHostMalloc of the chain buffers failed"); return GAMDP_ENOMEM; }
-        c->cap_hchain = total + total / 4;
+        if (hipHostMalloc(&c->h_chain, off_out + off_out / 4) != hipSuccess) { c->set_error("hipHostMalloc of the chain buffers failed"); return GAMDP_ENOMEM; }
+        c->cap_hchain = off_out + off_out / 4;
     }
+    if (mtotal > c->cap_mirror) {
+        if (c->h_mirror) (void)hipHostFree(c->h_mirror);
+        c->h_mirror = nullptr; c->cap_mirror = 0;
+        const u64 want = mtotal + mtotal / 4;
+        if (hipHostMalloc(&c->h_mirror, want, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { c->set_error("hipHostMalloc of the chain mirror failed"); return GAMDP_ENOMEM; }
+        c->cap_mirror = want;
+    }
+    void* d_mirror = nullptr;
+    if (hipHostGetDevicePointer(&d_mirror, c->h_mirror, 0) != hipSuccess) { c->set_error("hipHostGetDevicePointer failed"); return GAMDP_EHIP; }
+    if (!c->chain_stream) {
+        // A stream of its own priority class: the runtime multiplexes the streams of one class over a few hardware queues, and a
+        // round loop whose stream shares the chain launch's queue waits for the whole launch (measured: two of ten cohorts sat
+        // 27 ms behind it).  The lowest class: the launch is resident at once, the round loops' small launches go ahead of nothing.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&c->chain_stream, hipStreamNonBlocking, least) != hipSuccess) { c->set_error("hipStreamCreate failed"); return GAMDP_EHIP; }
+    }
+    // the flags: cleared for every launch (the layout moves with the call's sizes, so what lies there may be an earlier call's
+    // records), and raised to a value that changes from launch to launch
+    std::memset((uint8_t*)c->h_mirror + mo_done, 0, n_mb * sizeof(u32));
+    if (++c->chain_epoch == 0) c->chain_epoch = 1;
     uint8_t* const h = (uint8_t*)c->h_chain;
     uint8_t* const d = (uint8_t*)c->d_chain;
+    uint8_t* const hm = (uint8_t*)c->h_mirror;
+    uint8_t* const dm = (uint8_t*)d_mirror;
     DevMB* hmb = (DevMB*)(h + off_mb);
     DevBlk* hbk = (DevBlk*)(h + off_blk);
-    std::memset(h + off_cur, 0, 256);
+    run.q_of.assign(M.size(), ~0u);
     u32 blk_at = 0;
     for (size_t q = 0; q < n_mb; q++) {
         const Machine& m = M[act[order[q]]];
         const gamdp_mb_in& in = *m.in;
+        run.q_of[act[order[q]]] = (u32)q;
         DevMB& x = hmb[q];
         x.a2 = ms->fwd[in.m_id].p2; x.an = ms->fwd[in.m_id].pn;
         x.b2 = ss->fwd[in.s_id].p2; x.bn = ss->fwd[in.s_id].pn;
@@ -455,80 +520,158 @@ int run_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const Seq
     const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
     const u32 ypad = (u32)(((2 * band + 2 + 63) / 64) * 64);
     const u64 slotw = dirw + 4ull * ypad;
-    if (c->arena_budget() == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
-    const u64 fit = c->arena_call() / (slotw * sizeof(u32));
+    const u64 fit = arena / (slotw * sizeof(u32));
     if (fit == 0) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
     const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // workgroups per launch: each owns a slot
     const u64 need_scratch = slotw * n_slots;
-    if (need_scratch > c->cap_scratch) {
-        if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->cap_scratch = 0; }
-        if (hipMalloc(&c->d_scratch, need_scratch * sizeof(u32)) != hipSuccess) { c->d_scratch = nullptr; c->set_error("hipMalloc of scratch arena failed"); return GAMDP_ENOMEM; }
-        c->cap_scratch = need_scratch;
+    if (need_scratch > c->cap_chain_scratch) {
+        if (c->d_chain_scratch) { (void)hipFree(c->d_chain_scratch); c->d_chain_scratch = nullptr; c->cap_chain_scratch = 0; }
+        if (hipMalloc(&c->d_chain_scratch, need_scratch * sizeof(u32)) != hipSuccess) { c->d_chain_scratch = nullptr; c->set_error("hipMalloc of the chains' scratch slots failed"); return GAMDP_ENOMEM; }
+        c->cap_chain_scratch = need_scratch;
     }
     ChainParams cp;
     cp.mbs = (const DevMB*)(d + off_mb); cp.blks = (const DevBlk*)(d + off_blk); cp.n_mbs = (u32)n_mb;
-    cp.cursor = (u32*)(d + off_cur); cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
-    cp.scratch = c->d_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
+    cp.cursor = nullptr; cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
+    cp.scratch = c->d_chain_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
     cp.max_rows = (u32)std::min<u64>(std::max<u64>(1, w[order[0]]), 0x7fffffffu);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
+    cp.host_out = (ChainOut*)(dm + mo_out); cp.host_done = (u32*)(dm + mo_done); cp.host_audit = (DevResult*)(dm + mo_aud);
+    cp.epoch = c->chain_epoch;
+    if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
+    if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (int)has_n);
-    bool ok = hipMemcpyAsync(d, h, off_aud, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-    ok = ok && hipEventRecord(e0, c->stream) == hipSuccess;
+    run.n_mb = n_mb; run.band = band; run.hmb = hmb;
+    run.hout = (const ChainOut*)(hm + mo_out); run.done = (const volatile u32*)(hm + mo_done); run.haud = (const DevResult*)(hm + mo_aud);
+    run.epoch = cp.epoch; run.stream = c->chain_stream; run.dout = cp.out;
+    run.t_launch = std::chrono::steady_clock::now();
+    bool ok = hipMemcpyAsync(d, h, off_out, hipMemcpyHostToDevice, c->chain_stream) == hipSuccess;
+    ok = ok && hipEventRecord(run.e0, c->chain_stream) == hipSuccess;
     for (u64 first = 0; ok && first < n_mb; first += n_slots) {   // (one launch unless the arena holds fewer slots than there are merge blocks)
         cp.first_mb = (u32)first;
-        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)std::min<u64>(n_slots, n_mb - first), c->stream) == 0;
+        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)std::min<u64>(n_slots, n_mb - first), c->chain_stream) == 0;
     }
-    ok = ok && hipEventRecord(e1, c->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(h + off_out, d + off_out, total - off_out, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-    if (ok && diag().timing && diag().build) {
-        // diagnostics build: a watchdog instead of a blind wait -- after 5 s dump the progress markers of the chains and give up
-        const auto t0 = std::chrono::steady_clock::now();
-        while (hipStreamQuery(c->stream) == hipErrorNotReady) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
-                hipStream_t s2; (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-                std::vector<ChainOut> o(n_mb);
-                (void)hipMemcpyAsync(o.data(), d + off_out, n_mb * sizeof(ChainOut), hipMemcpyDeviceToHost, s2);
-                (void)hipStreamSynchronize(s2);
-                for (size_t q = 0; q < n_mb; q++) std::fprintf(stderr, "gamdp chain watchdog: mb %zu n_blocks %u: n_dp %u state 0x%x\n", q, hmb[q].n_blocks, o[q].n_dp, o[q].state);
-                std::fflush(stderr);
+    ok = ok && hipEventRecord(run.e1, c->chain_stream) == hipSuccess;
+    if (!ok) {
+        (void)hipStreamSynchronize(c->chain_stream);
+        (void)hipEventDestroy(run.e0); (void)hipEventDestroy(run.e1);
+        c->set_error(std::string("chain launch: ") + hipGetErrorString(hipGetLastError()));
+        return GAMDP_EHIP;
+    }
+    run.launched = true;
+    return 0;
+}
+
+// The host's machine of merge block `mi` over the records its chain left (after run.ended()).
+int replay_chain(Ctx* cc, const ChainRun& run, Machine& m, const u32 mi)
+{
+    static std::unordered_map<u32, std::vector<uint8_t>> no_cache;   // (never touched: the MAIN phase does not look at the slave's codes)
+    static std::mutex no_mu;
+    const u32 q = run.q_of[mi];
+    const DevMB& x = run.hmb[q];
+    const u32 n_dp = run.hout[q].n_dp;
+    u32 used = 0;
+    while (m.phase == Machine::MAIN) {
+        if (used >= n_dp) { cc->set_error("internal: the device's chain of merge block " + std::to_string(mi) + " is shorter than the host's"); return GAMDP_EHIP; }
+        ITask t;
+        m.pending(t, no_cache, no_mu);
+        u64 X = 0, cells = 0;
+        (void)preflight(m.mlen, m.slen, run.band, t.begin_a, t.end_a, t.begin_b, t.end_b, false, false, &X, &cells);
+        gamdp_result r;
+        fill_result(run.haud[x.audit_first + used], cells, r);
+        m.feed(r);
+        used++;
+    }
+    if (used != n_dp) { cc->set_error("internal: the device's chain of merge block " + std::to_string(mi) + " is longer than the host's"); return GAMDP_EHIP; }
+    return 0;
+}
+
+struct CohortStats { int rounds = 0; double pending_ms = 0, align_ms = 0, feed_ms = 0; int rc = 0; };
+
+// The round loop over one cohort of merge blocks on one context (= one host thread + one stream): every round collects the
+// pending find_alignment calls of its machines into ONE L0 batch, feeds the results back and advances the machines.  A
+// machine whose main chain is on the device (ChainRun) joins once its chain has ended and been replayed; until then the
+// rounds go on without it -- so the tails of the short chains are aligned while the long chains run, and a round is whatever
+// became ready while the last one was in flight.  Cohorts run concurrently: while one waits for its kernel, another builds
+// pending calls (findHits over contig tails, descriptor preparation) or feeds results -- host work hides behind GPU work.
+void run_cohort(Ctx* c, std::vector<Machine>& M, const std::vector<u32>& ids, std::unordered_map<u32, std::vector<uint8_t>>& rc_cache,
+                std::mutex& rc_mu, CohortStats& st, const ChainRun* run)
+{
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto msec = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::vector<ITask> tasks;
+    std::vector<u32> owner, first, waiting;
+    std::vector<gamdp_result> res;
+    const bool chained = run && run->launched;
+    if (chained)
+        for (u32 i : ids)
+            if (M[i].phase == Machine::MAIN && run->q_of[i] != ~0u) waiting.push_back(i);
+    bool drained = false;   // the chain launch is known to be complete
+    for (;;) {
+        const auto t0 = now();
+        if (!waiting.empty()) {
+            size_t keep = 0;
+            for (u32 i : waiting) {
+                if (run->ended(run->q_of[i])) {
+                    st.rc = replay_chain(c, *run, M[i], i);
+                    if (st.rc) return;
+                } else waiting[keep++] = i;
+            }
+            waiting.resize(keep);
+        }
+        owner.clear();
+        for (u32 i : ids)
+            if (M[i].phase != Machine::DONE && !(chained && M[i].phase == Machine::MAIN)) owner.push_back(i);
+        if (owner.empty()) {
+            if (waiting.empty()) break;
+            // nothing to do until a chain ends; a launch that is over without every flag up has failed
+            if (drained) { c->set_error("internal: the chain launch ended without handing over merge block " + std::to_string(waiting[0])); st.rc = GAMDP_EHIP; return; }
+            const hipError_t qs = hipStreamQuery(run->stream);
+            if (qs == hipSuccess) { drained = true; continue; }
+            if (qs != hipErrorNotReady) { c->set_error(std::string("chain kernel: ") + hipGetErrorString(qs)); st.rc = GAMDP_EHIP; return; }
+            if (diag().timing && diag().build && std::chrono::duration<double>(now() - run->t_launch).count() > 5.0) {
+                run->dump(stderr);   // diagnostics build: a watchdog instead of a blind wait
                 std::_Exit(3);
             }
+            for (int spin = 0; spin < 256; spin++) {
+                bool any = false;
+                for (u32 i : waiting) any = any || run->done[run->q_of[i]] == run->epoch;
+                if (any) break;
+                std::this_thread::yield();
+            }
+            continue;
         }
-    }
-    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
-    float ms_k = 0;
-    if (ok) (void)hipEventElapsedTime(&ms_k, e0, e1);
-    if (diag().timing) std::fprintf(stderr, "gamdp chain: kernel done ok=%d %.3f ms\n", (int)ok, ms_k);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (!ok) { c->set_error(std::string("chain kernel: ") + hipGetErrorString(hipGetLastError())); return GAMDP_EHIP; }
-    *kernel_ms = ms_k;
-    c->kernel_ms += ms_k; c->kernel_launches++;
-    // replay: the host's machines over the device's records
-    const ChainOut* hout = (const ChainOut*)(h + off_out);
-    const DevResult* haud = (const DevResult*)(h + off_aud);
-    std::unordered_map<u32, std::vector<uint8_t>> no_cache;
-    std::mutex no_mu;
-    for (size_t q = 0; q < n_mb; q++) {
-        Machine& m = M[act[order[q]]];
-        const DevMB& x = hmb[q];
-        u32 used = 0;
-        while (m.phase == Machine::MAIN) {
-            if (used >= hout[q].n_dp) { c->set_error("internal: the device's chain of merge block " + std::to_string(act[order[q]]) + " is shorter than the host's"); return GAMDP_EHIP; }
-            ITask t;
-            m.pending(t, no_cache, no_mu);
-            u64 X = 0, cells = 0;
-            (void)preflight(m.mlen, m.slen, band, t.begin_a, t.end_a, t.begin_b, t.end_b, false, false, &X, &cells);
-            gamdp_result r;
-            fill_result(haud[x.audit_first + used], cells, r);
-            m.feed(r);
-            used++;
+        // one call per machine -- two for a machine whose left AND right tails are due (independent of each other)
+        tasks.clear();
+        first.assign(owner.size(), 0);
+        for (size_t q = 0; q < owner.size(); q++) {
+            Machine& m = M[owner[q]];
+            first[q] = (u32)tasks.size();
+            tasks.push_back(ITask{});
+            m.pending(tasks.back(), rc_cache, rc_mu);
+            if (m.phase == Machine::LEFT && m.right_follows_left()) {
+                m.phase = Machine::RIGHT;          // (pending() looks at the phase and the main chain's end points only)
+                tasks.push_back(ITask{});
+                m.pending(tasks.back(), rc_cache, rc_mu);
+                m.phase = Machine::LEFT;
+            }
         }
-        if (used != hout[q].n_dp) { c->set_error("internal: the device's chain of merge block " + std::to_string(act[order[q]]) + " is longer than the host's"); return GAMDP_EHIP; }
+        const auto t1 = now();
+        res.assign(tasks.size(), gamdp_result{});
+        st.rc = c->align(tasks, res.data(), nullptr);
+        if (st.rc) return;
+        const auto t2 = now();
+        for (size_t q = 0; q < owner.size(); q++) {
+            Machine& m = M[owner[q]];
+            const u32 cnt = (q + 1 < owner.size() ? first[q + 1] : (u32)tasks.size()) - first[q];
+            m.feed(res[first[q]]);
+            if (cnt == 2 && m.phase == Machine::RIGHT) m.feed(res[first[q] + 1]);   // (not RIGHT: the left call threw, the machine is done)
+        }
+        const auto t3 = now();
+        st.pending_ms += msec(t0, t1); st.align_ms += msec(t1, t2); st.feed_ms += msec(t2, t3);
+        st.rounds++;
+        if (diag().timing && chained)
+            std::fprintf(stderr, "gamdp cohort %p: round %d at %.2f ms after the chain launch: %zu calls of %zu machines, pending %.2f ms, align %.2f ms, %zu still on the device\n",
+                         (void*)c, st.rounds, msec(run->t_launch, t0), tasks.size(), owner.size(), msec(t0, t1), msec(t1, t2), waiting.size());
     }
-    if (diag().timing) std::fprintf(stderr, "gamdp chain: replay done\n");
-    *launched = true;
-    return 0;
 }
 
 }  // namespace
@@ -564,13 +707,6 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
             weight[i] += (u64)frame_len(in[i].blocks[k].s_begin, in[i].blocks[k].s_end) * (2ull * band + 1);
     }
     const double k0_ms = c->kernel_ms; const u64 k0_n = c->kernel_launches;
-    // Main chains in one launch on the device; what remains for the round loop below are the tail alignments
-    bool chained = false;
-    double chain_ms = 0;
-    {
-        const int rc_chain = run_main_chains(c, M, ms, ss, band, &chained, &chain_ms);
-        if (rc_chain) return rc_chain;
-    }
     // Cohorts: host threads, each with its own context (stream, staging buffers, scratch arena) on this device; the merge
     // blocks are dealt by predicted cells (LPT), so the cohorts' chains have similar depth.  A round lasts as long as its
     // longest call, so smaller cohorts mean shorter rounds that overlap on the (nearly empty) GPU -- up to a point: 4 cohorts
@@ -597,13 +733,16 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         Ctx* c; int K;
         ~DivGuard() { c->arena_div = 1; for (int k = 1; k < K; k++) c->helpers[(size_t)k - 1]->arena_div = 1; }
     } div_guard{c, K};
-    c->arena_div = (u32)K;
+    // (half of the budget for the chain launch's scratch slots, the other half for the K round loops beside it)
+    c->arena_div = 2u * (u32)K;
     for (int k = 1; k < K; k++) {
         Ctx* h = c->helpers[(size_t)k - 1];
-        h->arena_limit = c->arena_limit; h->arena_share = c->arena_share; h->arena_div = (u32)K;
+        h->arena_limit = c->arena_limit; h->arena_share = c->arena_share; h->arena_div = 2u * (u32)K;
         h->trim_scratch();
     }
     c->trim_scratch();
+    const u64 chain_arena = c->arena_limit / (2ull * (u64)(c->arena_share ? c->arena_share : 1));
+    if (c->d_chain_scratch && c->cap_chain_scratch * sizeof(u32) > chain_arena) { (void)hipFree(c->d_chain_scratch); c->d_chain_scratch = nullptr; c->cap_chain_scratch = 0; }
     std::vector<u32> part(n, 0);
     if (K > 1) partition_lpt(weight.data(), n, K, part.data());
     std::vector<std::vector<u32>> ids((size_t)K);
@@ -615,11 +754,29 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     std::vector<CohortStats> cst((size_t)K);
     std::unordered_map<u32, std::vector<uint8_t>> rc_cache;
     std::mutex rc_mu;
+    // the main chains: one launch on the device, beside the round loops that take over what it hands back
+    ChainRun run;
+    {
+        const int rc_chain = launch_main_chains(c, M, ms, ss, band, chain_arena, run);
+        if (rc_chain) return rc_chain;
+    }
+    const bool chained = run.launched;
+    float chain_ms = 0, chain_at = 0;
+    struct FreeGuard {   // (see Ctx::defer_frees)
+        Ctx* c; int K;
+        void set(bool on) { c->defer_frees = on; for (int k = 1; k < K; k++) c->helpers[(size_t)k - 1]->defer_frees = on; }
+        ~FreeGuard() { set(false); c->flush_frees(); for (int k = 1; k < K; k++) c->helpers[(size_t)k - 1]->flush_frees(); }
+    } free_guard{c, K};
+    free_guard.set(chained);
     auto body = [&](int k) noexcept {
         Ctx* cc = k == 0 ? c : c->helpers[(size_t)k - 1];
         if (k > 0) { cc->kernel_ms = 0; cc->kernel_launches = 0; cc->ref_event = c->ref_event; }
         cc->interval_sink = &intervals[(size_t)k];
-        const int rc_k = guarded(cc, [&]() -> int { run_cohort(cc, M, ids[(size_t)k], rc_cache, rc_mu, cst[(size_t)k]); return 0; });
+        const int rc_k = guarded(cc, [&]() -> int {
+            if (hipSetDevice(cc->device) != hipSuccess) { cc->set_error("hipSetDevice failed"); return GAMDP_EHIP; }
+            run_cohort(cc, M, ids[(size_t)k], rc_cache, rc_mu, cst[(size_t)k], &run);
+            return 0;
+        });
         if (rc_k && !cst[(size_t)k].rc) cst[(size_t)k].rc = rc_k;
         cc->interval_sink = nullptr;
         if (k > 0) cc->ref_event = nullptr;  // borrowed
@@ -629,11 +786,13 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         for (int k = 1; k < K; k++) pool.start(body, k);
         body(0);
     }
+    const int rc_fin = run.finish(c, &chain_at, &chain_ms);   // (also after an error in a cohort: the launch owns buffers of the context)
     for (int k = 0; k < K; k++)
         if (cst[(size_t)k].rc) {
             if (k > 0) c->set_error(c->helpers[(size_t)k - 1]->err);
             return cst[(size_t)k].rc;
         }
+    if (rc_fin) return rc_fin;
     // statistics of this call; the helpers' kernel time is accounted to the caller's context
     gamdp_l1_stats& S = c->last_l1;
     S = gamdp_l1_stats{};
@@ -646,6 +805,7 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         S.host_pending_ms += cst[(size_t)k].pending_ms; S.host_feed_ms += cst[(size_t)k].feed_ms;
         all.insert(all.end(), intervals[(size_t)k].begin(), intervals[(size_t)k].end());
     }
+    if (chained) all.emplace_back(chain_at, chain_at + chain_ms);
     S.launches = (uint32_t)(c->kernel_launches - k0_n);
     S.kernel_sum_ms = c->kernel_ms - k0_ms;
     std::sort(all.begin(), all.end());
@@ -656,7 +816,6 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         else { S.gpu_busy_ms += cur_hi - cur_lo; cur_lo = iv.first; cur_hi = iv.second; }
     }
     if (cur_hi >= cur_lo) S.gpu_busy_ms += cur_hi - cur_lo;
-    S.gpu_busy_ms += chain_ms;   // (the chain launch runs before the round loop's reference event)
     S.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (gamdp::diag().timing)
         std::fprintf(stderr, "gamdp_align_merge_blocks: %zu merge blocks, %d cohorts, %u rounds, %u launches: wall %.2f ms, GPU busy %.2f ms (kernels %.2f ms), pending %.2f ms, feed %.2f ms\n",

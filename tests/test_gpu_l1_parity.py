@@ -169,3 +169,18 @@ def test_standalone_tool_through_to_gam_fasta(tmp_path):
     assert open(tmp_path / "run.gam.fasta").read() == PO.render_fasta(want)
     assert open(tmp_path / "run.pctgs").read() == PO.render_descriptors(want, merged, ["m%d" % i for i in range(len(scs))],
                                                                       ["s%d" % i for i in range(len(scs))])
+
+
+def test_round_loop_for_every_call_in_a_fresh_process():
+    """The main chains of the merge blocks run on the device in one launch (k_chain) and the host replays its state machines
+    over the records; GAMDP_L1_ROUNDS=1 keeps every call in the round loop (what other bands than 150 take anyway).  Both
+    must give what the oracle gives: the merge-block tests of this file and the GAGE-shaped ones once more in a child."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_L1_ROUNDS"):
+        pytest.skip("already inside the child")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GAMDP_L1_ROUNDS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), os.path.join(here, "test_gpu_gage.py"),
+                        "-k", "merge_blocks_match_oracle or single_merge_block or reference_exception or gage"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
