@@ -183,6 +183,7 @@ struct DevMB {
     u32 audit_first;               // its first record in the audit list (room for 2 * n_blocks)
     u32 rows;                      // sum of its slave frames: the rows one pass of the chain fills
     u32 try_rev;                   // orientation of the first attempt
+    u32 has_n;                     // one of its two contigs holds an N: the chain runs the N-aware cells (12% slower)
 };
 struct ChainOut { u32 n_dp; u32 state; };   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
 struct ChainParams {
@@ -196,6 +197,7 @@ struct ChainParams {
     // records and its ChainOut there and then raises its flag (done[mi] = epoch, system-scope release), so the host takes a
     // merge block on (replay, tail alignments) while longer chains are still going
     DevResult* host_audit; ChainOut* host_out; u32* host_done; u32 epoch;
+    u32 two_waves;                 // k_chain2: a workgroup of two wavefronts (fill | walk) with two scratch slots of slot_words each
 };
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int
 

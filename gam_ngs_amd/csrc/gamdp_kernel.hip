@@ -55,10 +55,10 @@ __shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise
 #include "kernel_finish.inc"
 
 // ---- the whole task -------------------------------------------------------------------------------
+// phases A and B: row 0 and the sweep; leaves the task's values in t for the end-cell search and the walk
 template <int C, int CE, bool HASN>
-__device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane, const bool lrpt)
+__device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane, const bool lrpt, Tk& t)
 {
-    Tk t;
     t.a2 = as_global(dt.a2); t.an = as_global(dt.an); t.b2 = as_global(dt.b2); t.bn = as_global(dt.bn);
     t.a_base = dt.a_base; t.b_base = dt.b_base; t.end_a = dt.end_a;
     t.alen = dt.alen; t.blen = dt.blen; t.begin_a = dt.begin_a; t.begin_b = dt.begin_b;
@@ -138,6 +138,13 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
             ++blk;
         }
     }
+}
+
+template <int C, int CE, bool HASN>
+__device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane, const bool lrpt)
+{
+    Tk t;
+    fill_task<C, CE, HASN>(dt, p, slot, lane, lrpt, t);
     if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);   // end cell + walk: few vector instructions, whoever still fills goes first
     finish_task<C, CE, HASN>(&t, &dt, &p, lane);
 }
@@ -700,6 +707,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
 // owns the scratch slot of its index.  (A persistent-wavefront version with an atomic cursor hung on the device after the last
 // call of every chain -- its loop exit had been compiled lane-wise; not pursued: a merge-block call has far fewer merge blocks
 // than the scratch arena has room for slots, and the host launches in pieces when it does not.)
+// HASN = false: a launch in which no contig holds an N; true: every chain picks its cells by its own two contigs.
 template <bool HASN>
 __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainParams cp)
 {
@@ -710,7 +718,158 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
     p.ckpt_off = 0; p.bnd_off = 0; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
-    run_chain<HASN>(cp, p, mi, slot, lane);
+    if constexpr (HASN) {
+        if (uni((int)cp.mbs[mi].has_n) != 0) run_chain<true>(cp, p, mi, slot, lane);
+        else run_chain<false>(cp, p, mi, slot, lane);
+    } else run_chain<false>(cp, p, mi, slot, lane);
+}
+
+// ---- the same chain by two wavefronts: one fills, one walks ------------------------------------------------------------------
+// A lone wavefront issues one instruction every ~5 cycles whatever it does, and a fifth of a chain's instructions are the end-cell
+// search and the walk (measured, tools/r03_probe8.sh: 50 kb band-150 calls one per CU, 3.81 ms fill + 1.00 ms walk).  The next
+// call of a chain needs one thing from the walk of this one: the last match (PctgBuilder.cc:1660-1667), which is the FIRST match
+// the walk meets.  So the workgroup has two wavefronts and two scratch slots: wavefront 0 fills call k + 1 into one slot while
+// wavefront 1 walks call k in the other (ChainMail, kernel_finish.inc).  Same calls, same records, same order in the audit list.
+template <bool HASN>
+__device__ __forceinline__ void chain_filler(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slots, const int lane)
+{
+    const DevMB* mb = unip(cp.mbs + mi);
+    const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
+    const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
+    const u64 align_thr = (u64)uni64((int64_t)mb->align_thr);
+    const u32 first_blk = (u32)uni((int)mb->first_blk), n = (u32)uni((int)mb->n_blocks), audit_first = (u32)uni((int)mb->audit_first);
+    const u32 band = cp.band;
+    bool try_rev = uni((int)mb->try_rev) != 0;
+    auto frame_len = [](const int32_t b, const int32_t e) -> int32_t { return e < b ? 0 : e - b + 1; };   // Frame.cc:124-127
+    u32 n_dp = 0, state = 1;
+    int sent = 0;   // calls handed to the walker so far (the chain's calls that need a DP)
+    for (int attempt = 0;; ) {
+        int64_t cur_ms = (int64_t)m_start;
+        int64_t cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);   // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
+        u64 last_a = 0, last_b = 0;
+        bool settled_bad = false, thrown = false;
+        int rows_left = uni((int)mb->rows);
+        // (the walker is idle here: every call handed over so far is done)
+        if (lane == 0) { s_mail.bad = 0; s_mail.sum_lo = 0; s_mail.sum_hi = 0; }
+        for (u32 k = 0; k < n; ++k) {
+            const DevBlk* bk = unip(cp.blks + first_blk + k);
+            const int32_t cm_b = uni(bk->m_begin), cm_e = uni(bk->m_end), cs_b = uni(bk->s_begin), cs_e = uni(bk->s_end);
+            const int32_t ml = frame_len(cm_b, cm_e), sl = frame_len(cs_b, cs_e);
+            if (k > 0) {  // :1660-1667
+                const int32_t pm_b = uni(bk[-1].m_begin), pm_e = uni(bk[-1].m_end), ps_b = uni(bk[-1].s_begin), ps_e = uni(bk[-1].s_end);
+                const int32_t mgap = pm_b <= cm_b ? (cm_b - pm_e - 1) : (pm_b - cm_e - 1);
+                const int32_t sgap = ps_b <= cs_b ? (cs_b - ps_e - 1) : (ps_b - cs_e - 1);
+                cur_ms = (int64_t)(last_a + (u64)(int64_t)mgap); if (cur_ms < 0) cur_ms = 0;
+                cur_ss = (int64_t)(last_b + (u64)(int64_t)sgap); if (cur_ss < 0) cur_ss = 0;
+            }
+            const u64 begin_a = (u64)cur_ms, end_a = (u64)(cur_ms + ml - 1), begin_b = (u64)cur_ss, end_b = (u64)(cur_ss + sl - 1);
+            set_prio_by_remaining(rows_left, (int)cp.max_rows);
+            rows_left -= sl;
+            u64 X = 0, cells = 0;
+            const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
+            const u32 idx = audit_first + n_dp;
+            u32 status;
+            if (st != 0) {   // settled without a DP, exactly as the host settles it (Ctx::align)
+                DevResult r;
+                r.begin_a = r.begin_b = r.score = 0; r.n_match = r.length = 0;
+                r.first_a = r.first_b = r.last_a = r.last_b = 0;
+                r.flags = (u32)st << 8;
+                if (lane == 0) cp.audit[idx] = r;
+                status = (u32)st;
+                last_a = last_b = 0;
+                settled_bad = true;   // (never ST_OK: an empty alignment, or one of the two that stop the machine)
+            } else {
+                const int par = sent & 1;
+                mail_wait_ge(&s_mail.done, sent - 1);   // the slot's last call (two calls back) has been walked
+                DevTask dt;
+                dt.a2 = mb->a2; dt.an = mb->an;
+                dt.b2 = try_rev ? mb->b2rc : mb->b2; dt.bn = try_rev ? mb->bnrc : mb->bn;
+                dt.a_base = 0; dt.b_base = 0;
+                dt.end_a = (int64_t)(end_a < (1ull << 40) ? end_a : (1ull << 40));
+                dt.alen = (int32_t)mlen; dt.blen = (int32_t)slen;
+                dt.begin_a = (int32_t)begin_a; dt.begin_b = (int32_t)begin_b;
+                dt.X = (int32_t)X; dt.band = (int32_t)band;
+                dt.flags = 0; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
+                Tk t;
+                fill_task<5, 0, HASN>(dt, p, slots + (u64)par * cp.slot_words, lane, false, t);
+                if (lane == 0) { s_mail.tk[par] = t; s_mail.dt[par] = dt; }
+                ++sent;
+                mail_post(&s_mail.filled, sent, lane);   // (after the wavefront's stores: rows, directions, side buffers)
+                mail_wait_ge(&s_mail.early, sent);
+                const u32 fl = (u32)uni(s_mail.e_flags);
+                status = fl >> 8;
+                if (status == ST_OK) { last_a = (u64)(int64_t)uni(s_mail.e_last_a); last_b = (u64)(int64_t)uni(s_mail.e_last_b); }
+                else last_a = last_b = 0;   // EMPTY: MyAlignment(), last match (0, 0)
+            }
+            ++n_dp;
+            if (status == ST_OUT_OF_RANGE || status == 3u) { thrown = true; break; }   // the reference throws / undefined: the machine stops (finish_bad)
+        }
+        mail_wait_ge(&s_mail.done, sent);   // every walk of this attempt has ended: is_good(vector), :1711-1724
+        const bool all_good = !settled_bad && uni(s_mail.bad) == 0;
+        const u64 sumlen = ((u64)(u32)uni((int)s_mail.sum_hi) << 32) | (u64)(u32)uni((int)s_mail.sum_lo);
+        if (thrown) { state = 2; break; }
+        if (all_good && sumlen >= align_thr) { state = try_rev ? 0x100u : 0u; break; }
+        if (++attempt == 2) { state = 1; break; }                                          // :1512
+        try_rev = !try_rev;
+    }
+    if (lane == 0) s_mail.quit = 1;
+    mail_post(&s_mail.filled, sent + 1, lane);   // (wakes the walker; nothing behind it)
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.out[mi] = o; }
+    // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        const u32* src = reinterpret_cast<const u32*>(cp.audit + audit_first);
+        u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
+        const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
+        for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.host_out[mi] = o; }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
+    if (lane == 0) __hip_atomic_store(cp.host_done + mi, cp.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <bool HASN>
+__device__ __forceinline__ void chain_walker(const LaunchParams& p, const int lane)
+{
+    __builtin_amdgcn_s_setprio(3);   // few instructions, and the filler waits for the first of them
+    for (int w = 0;; ++w) {
+        mail_wait_ge(&s_mail.filled, w + 1);
+        if (uni(s_mail.quit) != 0 && mail_load(&s_mail.filled) == w + 1) break;   // (quit is posted with the count one past the last call)
+        const int par = w & 1;
+        WalkCarry wc;
+        end_cell<5, true>(&s_mail.tk[par], lane, &wc);
+        wc.early_seq = w + 1;
+        (void)finish_walk<5, 0, HASN, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
+    }
+}
+
+template <bool HASN>
+__global__ __launch_bounds__(128, GAMDP_WAVES_PER_SIMD) void k_chain2(const ChainParams cp)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const u32 mi = cp.first_mb + blockIdx.x;
+    u32* slots = cp.scratch + (u64)blockIdx.x * 2u * cp.slot_words;
+    LaunchParams p;
+    p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
+    p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
+    p.ckpt_off = 0; p.bnd_off = 0; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    if (threadIdx.x == 0) { s_mail.filled = 0; s_mail.early = 0; s_mail.done = 0; s_mail.quit = 0; }
+    __syncthreads();
+    const bool mb_n = HASN && uni((int)cp.mbs[mi].has_n) != 0;
+    if (wave == 0) {
+        if constexpr (HASN) {
+            if (mb_n) chain_filler<true>(cp, p, mi, slots, lane);
+            else chain_filler<false>(cp, p, mi, slots, lane);
+        } else chain_filler<false>(cp, p, mi, slots, lane);
+    } else {
+        if constexpr (HASN) {
+            if (mb_n) chain_walker<true>(p, lane);
+            else chain_walker<false>(p, lane);
+        } else chain_walker<false>(p, lane);
+    }
 }
 
 }  // namespace
@@ -719,6 +878,10 @@ int launch_chain(const ChainParams& p, bool has_n, unsigned n_slots, void* strea
 {
     ChainParams cp = p;
     void* args[] = {&cp};
+    if (cp.two_waves) {
+        const void* f = has_n ? (const void*)k_chain2<true> : (const void*)k_chain2<false>;
+        return (int)hipLaunchKernel(f, dim3(n_slots), dim3(128), args, 0, static_cast<hipStream_t>(stream));
+    }
     const void* f = has_n ? (const void*)k_chain<true> : (const void*)k_chain<false>;
     return (int)hipLaunchKernel(f, dim3(n_slots), dim3(64), args, 0, static_cast<hipStream_t>(stream));
 }

@@ -509,6 +509,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
         x.first_blk = blk_at; x.n_blocks = in.n_blocks; x.audit_first = 2 * blk_at;
         x.rows = (u32)std::min<u64>(w[order[q]], 0x7fffffffu);
         x.try_rev = m.try_rev ? 1u : 0u;
+        x.has_n = (ms->has_n[in.m_id] || ss->has_n[in.s_id] || diag().force_n) ? 1u : 0u;
         for (u32 k = 0; k < in.n_blocks; k++) {
             const gamdp_block& b = m.blk(k);
             hbk[blk_at + k] = DevBlk{b.m_begin, b.m_end, b.s_begin, b.s_end};
@@ -520,10 +521,14 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
     const u32 ypad = (u32)(((2 * band + 2 + 63) / 64) * 64);
     const u64 slotw = dirw + 4ull * ypad;
-    const u64 fit = arena / (slotw * sizeof(u32));
+    // k_chain2: two wavefronts and two slots per merge block (one call is walked while the next is filled); GAMDP_L1_ONE_WAVE=1
+    // keeps the one-wavefront kernel (A/B)
+    static const bool one_wave = std::getenv("GAMDP_L1_ONE_WAVE") != nullptr;
+    const u64 per_wg = one_wave ? 1 : 2;
+    const u64 fit = arena / (per_wg * slotw * sizeof(u32));
     if (fit == 0) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
-    const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // workgroups per launch: each owns a slot
-    const u64 need_scratch = slotw * n_slots;
+    const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // workgroups per launch: each owns its slot(s)
+    const u64 need_scratch = per_wg * slotw * n_slots;
     if (need_scratch > c->cap_chain_scratch) {
         if (c->d_chain_scratch) { (void)hipFree(c->d_chain_scratch); c->d_chain_scratch = nullptr; c->cap_chain_scratch = 0; }
         if (hipMalloc(&c->d_chain_scratch, need_scratch * sizeof(u32)) != hipSuccess) { c->d_chain_scratch = nullptr; c->set_error("hipMalloc of the chains' scratch slots failed"); return GAMDP_ENOMEM; }
@@ -536,6 +541,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     cp.max_rows = (u32)std::min<u64>(std::max<u64>(1, w[order[0]]), 0x7fffffffu);
     cp.host_out = (ChainOut*)(dm + mo_out); cp.host_done = (u32*)(dm + mo_done); cp.host_audit = (DevResult*)(dm + mo_aud);
     cp.epoch = c->chain_epoch;
+    cp.two_waves = one_wave ? 0u : 1u;
     if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (int)has_n);
