@@ -65,8 +65,11 @@ def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150):
     st = L.L1Stats()
     t1 = time.perf_counter()
     for _ in range(steps):
+        ts = time.perf_counter()
         step()
         ctx.lib.gamdp_ctx_l1_stats(ctx.handle, C.byref(st))
+        if os.environ.get("GAMDP_BENCH_L1_STEPS"):
+            print("step: %.3f ms around the call, %.3f ms inside the library" % ((time.perf_counter() - ts) * 1e3, st.wall_ms), file=sys.stderr)
         acc["wall"] += st.wall_ms; acc["busy"] += st.gpu_busy_ms; acc["ksum"] += st.kernel_sum_ms
         acc["pend"] += st.host_pending_ms; acc["feed"] += st.host_feed_ms
     dt = (time.perf_counter() - t1) / steps

@@ -185,23 +185,27 @@ struct DevMB {
     u32 try_rev;                   // orientation of the first attempt
     u32 has_n;                     // one of its two contigs holds an N: the chain runs the N-aware cells (12% slower)
 };
-struct ChainOut { u32 n_dp; u32 state; };   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
+struct ChainOut { u32 n_dp; u32 state; u32 t_begin, t_end; };   // t_*: the device's 100 MHz clock (low word) when the chain's workgroup started / ended (timing diagnostics)
+//   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
 struct ChainParams {
     const DevMB* mbs; const DevBlk* blks; u32 n_mbs;
     u32 first_mb;                  // the launch takes merge blocks first_mb .. first_mb + grid - 1
     u32* cursor;
     DevResult* audit; ChainOut* out;
     u32* scratch; u64 slot_words, dir_words; u32 ypad; u32 band;
+    u64 ckpt_off, bnd_off;         // word offsets inside a slot of the direction-free fill's stores (0 = directions everywhere), as in LaunchParams
     u32 max_rows;                  // the largest DevMB::rows of the call: chains with many rows left go first (set_prio_by_remaining)
     // the host's view while the launch runs (pinned, coherent host memory, device pointers): a chain that ends copies its
     // records and its ChainOut there and then raises its flag (done[mi] = epoch, system-scope release), so the host takes a
     // merge block on (replay, tail alignments) while longer chains are still going
     DevResult* host_audit; ChainOut* host_out; u32* host_done; u32 epoch;
-    u32 two_waves;                 // k_chain2: a workgroup of two wavefronts (fill | walk) with two scratch slots of slot_words each
+    u32 two_waves;                 // k_chain2: a workgroup of one filling and several walking wavefronts with chain_slots_per_workgroup() scratch slots of slot_words each
 };
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int
+int chain_slots_per_workgroup();   // scratch slots a k_chain2 workgroup goes round (1 + its walker wavefronts)
 
 int kernel_cols(int kid);
+bool kernel_dirfree(int kid);          // its fast blocks can run without directions (when the launch provides ckpt_off / bnd_off)
 int kernel_dir_block_words(int kid);  // words per block (16 row-times) of a task's direction image
 // launches on `stream`; returns hipError_t as int
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, unsigned dyn_lds, void* stream);

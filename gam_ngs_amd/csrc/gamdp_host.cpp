@@ -305,7 +305,7 @@ static int grow(Ctx* ctx, T*& ptr, u64& cap, u64 need)
 {
     if (need <= cap) return 0;
     if (ptr) { ctx->free_dev(ptr); ptr = nullptr; cap = 0; }
-    u64 want = need + need / 4;
+    u64 want = need + (ctx->defer_frees ? need + 1024 : need / 4);   // (a round loop beside a chain launch: see the scratch arena in Ctx::align)
     if (hipMalloc(&ptr, want * sizeof(T)) != hipSuccess) {
         if (hipMalloc(&ptr, need * sizeof(T)) != hipSuccess) {
             ctx->set_error("hipMalloc of " + std::to_string(need * sizeof(T)) + " bytes failed");
@@ -594,7 +594,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             u64 ckpt_words = 0, bnd_words = 0;
             const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
             const bool pair = kid == K_P17_CE4 || kid == K_O19_CE15;   // ... and, for the pairs (of tasks / of quads), its own direction words
-            if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
+            // (the one-task band-150 kernels: GAMDP_NO_DF5=1 keeps their directions, A/B)
+            static const bool no_df5 = std::getenv("GAMDP_NO_DF5") != nullptr;
+            const bool c5 = kid == K_C5_CE0 || kid == K_C5_CE0_N;
+            if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1 || (c5 && kernel_dirfree(kid) && !no_df5)) {
                 const u64 cw = (u64)kernel_dir_block_words(kid), nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * (u64)kernel_ckpt_words(kid);
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);
@@ -660,6 +663,9 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         for (auto& L : launches) need_scratch = std::max(need_scratch, L.slot_words * L.n_slots);
         if (need_scratch > cap_scratch) {
             if (d_scratch) { free_dev(d_scratch); d_scratch = nullptr; cap_scratch = 0; }
+            // a round loop beside a chain launch: what a round holds depends on which chains have ended, so its needs move from
+            // call to call -- room to spare (inside the call's share) instead of a hipMalloc every few calls (1.5 ms each)
+            if (defer_frees) need_scratch = std::max(need_scratch, std::min<u64>(2 * need_scratch, arena_call / sizeof(u32)));
             if (hipMalloc(&d_scratch, need_scratch * sizeof(u32)) != hipSuccess) {
                 // a call on this context alone after calls that shared the device: its idle helper contexts may still
                 // hold their shares of the budget

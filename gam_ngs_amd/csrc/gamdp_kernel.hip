@@ -599,6 +599,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align_q(const Laun
 template <bool HASN>
 __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slot, const int lane)
 {
+    const u32 t_begin = (u32)wall_clock64();
     const DevMB* mb = unip(cp.mbs + mi);
     const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
@@ -688,7 +689,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         try_rev = !try_rev;
     }
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.out[mi] = o; }
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.out[mi] = o; }
     // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
@@ -696,7 +697,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
         const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
         for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
-        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.host_out[mi] = o; }
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
-    p.ckpt_off = 0; p.bnd_off = 0; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.ckpt_off = cp.ckpt_off; p.bnd_off = cp.bnd_off; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
     if constexpr (HASN) {
         if (uni((int)cp.mbs[mi].has_n) != 0) run_chain<true>(cp, p, mi, slot, lane);
         else run_chain<false>(cp, p, mi, slot, lane);
@@ -733,6 +734,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
 template <bool HASN>
 __device__ __forceinline__ void chain_filler(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slots, const int lane)
 {
+    const u32 t_begin = (u32)wall_clock64();
     const DevMB* mb = unip(cp.mbs + mi);
     const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
@@ -749,8 +751,8 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         u64 last_a = 0, last_b = 0;
         bool settled_bad = false, thrown = false;
         int rows_left = uni((int)mb->rows);
-        // (the walker is idle here: every call handed over so far is done)
-        if (lane == 0) { s_mail.bad = 0; s_mail.sum_lo = 0; s_mail.sum_hi = 0; }
+        // (the walkers are idle here: every call handed over so far is done)
+        if (lane == 0) { s_mail.bad = 0; s_mail.sum = 0; }
         for (u32 k = 0; k < n; ++k) {
             const DevBlk* bk = unip(cp.blks + first_blk + k);
             const int32_t cm_b = uni(bk->m_begin), cm_e = uni(bk->m_end), cs_b = uni(bk->s_begin), cs_e = uni(bk->s_end);
@@ -779,8 +781,8 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
                 last_a = last_b = 0;
                 settled_bad = true;   // (never ST_OK: an empty alignment, or one of the two that stop the machine)
             } else {
-                const int par = sent & 1;
-                mail_wait_ge(&s_mail.done, sent - 1);   // the slot's last call (two calls back) has been walked
+                const int par = sent % CH_NS;
+                mail_wait_ge(&s_mail.done_of[par], sent - CH_NS + 1);   // the slot's last call (CH_NS calls back) has been walked
                 DevTask dt;
                 dt.a2 = mb->a2; dt.an = mb->an;
                 dt.b2 = try_rev ? mb->b2rc : mb->b2; dt.bn = try_rev ? mb->bnrc : mb->bn;
@@ -795,27 +797,27 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
                 if (lane == 0) { s_mail.tk[par] = t; s_mail.dt[par] = dt; }
                 ++sent;
                 mail_post(&s_mail.filled, sent, lane);   // (after the wavefront's stores: rows, directions, side buffers)
-                mail_wait_ge(&s_mail.early, sent);
-                const u32 fl = (u32)uni(s_mail.e_flags);
+                mail_wait_ge(&s_mail.early_of[par], sent);
+                const u32 fl = (u32)uni(s_mail.e_flags[par]);
                 status = fl >> 8;
-                if (status == ST_OK) { last_a = (u64)(int64_t)uni(s_mail.e_last_a); last_b = (u64)(int64_t)uni(s_mail.e_last_b); }
+                if (status == ST_OK) { last_a = (u64)(int64_t)uni(s_mail.e_last_a[par]); last_b = (u64)(int64_t)uni(s_mail.e_last_b[par]); }
                 else last_a = last_b = 0;   // EMPTY: MyAlignment(), last match (0, 0)
             }
             ++n_dp;
             if (status == ST_OUT_OF_RANGE || status == 3u) { thrown = true; break; }   // the reference throws / undefined: the machine stops (finish_bad)
         }
-        mail_wait_ge(&s_mail.done, sent);   // every walk of this attempt has ended: is_good(vector), :1711-1724
+        mail_wait_ge(&s_mail.n_done, sent);   // every walk of this attempt has ended: is_good(vector), :1711-1724
         const bool all_good = !settled_bad && uni(s_mail.bad) == 0;
-        const u64 sumlen = ((u64)(u32)uni((int)s_mail.sum_hi) << 32) | (u64)(u32)uni((int)s_mail.sum_lo);
+        const u64 sumlen = (u64)uni64((int64_t)s_mail.sum);
         if (thrown) { state = 2; break; }
         if (all_good && sumlen >= align_thr) { state = try_rev ? 0x100u : 0u; break; }
         if (++attempt == 2) { state = 1; break; }                                          // :1512
         try_rev = !try_rev;
     }
-    if (lane == 0) s_mail.quit = 1;
-    mail_post(&s_mail.filled, sent + 1, lane);   // (wakes the walker; nothing behind it)
+    if (lane == 0) { s_mail.total = sent; s_mail.quit = 1; }
+    mail_post(&s_mail.filled, sent + CH_NW, lane);   // (wakes every walker, whichever call it waits for; nothing behind those counts)
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.out[mi] = o; }
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.out[mi] = o; }
     // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
@@ -823,7 +825,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
         const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
         for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
-        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; cp.host_out[mi] = o; }
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
@@ -834,10 +836,13 @@ template <bool HASN>
 __device__ __forceinline__ void chain_walker(const LaunchParams& p, const int lane)
 {
     __builtin_amdgcn_s_setprio(3);   // few instructions, and the filler waits for the first of them
-    for (int w = 0;; ++w) {
+    for (;;) {
+        int w = 0;
+        if (lane == 0) w = __hip_atomic_fetch_add(&s_mail.claim, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        w = __builtin_amdgcn_readfirstlane(w);
         mail_wait_ge(&s_mail.filled, w + 1);
-        if (uni(s_mail.quit) != 0 && mail_load(&s_mail.filled) == w + 1) break;   // (quit is posted with the count one past the last call)
-        const int par = w & 1;
+        if (uni(s_mail.quit) != 0 && w >= uni(s_mail.total)) break;   // (quit is posted with a count past every waiting walker's call)
+        const int par = w % CH_NS;
         WalkCarry wc;
         end_cell<5, true>(&s_mail.tk[par], lane, &wc);
         wc.early_seq = w + 1;
@@ -846,17 +851,20 @@ __device__ __forceinline__ void chain_walker(const LaunchParams& p, const int la
 }
 
 template <bool HASN>
-__global__ __launch_bounds__(128, GAMDP_WAVES_PER_SIMD) void k_chain2(const ChainParams cp)
+__global__ __launch_bounds__(64 * (1 + CH_NW), GAMDP_WAVES_PER_SIMD) void k_chain2(const ChainParams cp)
 {
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
     const u32 mi = cp.first_mb + blockIdx.x;
-    u32* slots = cp.scratch + (u64)blockIdx.x * 2u * cp.slot_words;
+    u32* slots = cp.scratch + (u64)blockIdx.x * (u64)CH_NS * cp.slot_words;
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
-    p.ckpt_off = 0; p.bnd_off = 0; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
-    if (threadIdx.x == 0) { s_mail.filled = 0; s_mail.early = 0; s_mail.done = 0; s_mail.quit = 0; }
+    p.ckpt_off = cp.ckpt_off; p.bnd_off = cp.bnd_off; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    if (threadIdx.x == 0) {
+        s_mail.filled = 0; s_mail.quit = 0; s_mail.total = 0; s_mail.claim = 0; s_mail.n_done = 0;
+        for (int k = 0; k < CH_NS; ++k) { s_mail.early_of[k] = 0; s_mail.done_of[k] = 0; }
+    }
     __syncthreads();
     const bool mb_n = HASN && uni((int)cp.mbs[mi].has_n) != 0;
     if (wave == 0) {
@@ -874,13 +882,15 @@ __global__ __launch_bounds__(128, GAMDP_WAVES_PER_SIMD) void k_chain2(const Chai
 
 }  // namespace
 
+int chain_slots_per_workgroup() { return CH_NS; }
+
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_slots, void* stream)
 {
     ChainParams cp = p;
     void* args[] = {&cp};
     if (cp.two_waves) {
         const void* f = has_n ? (const void*)k_chain2<true> : (const void*)k_chain2<false>;
-        return (int)hipLaunchKernel(f, dim3(n_slots), dim3(128), args, 0, static_cast<hipStream_t>(stream));
+        return (int)hipLaunchKernel(f, dim3(n_slots), dim3(64 * (1 + CH_NW)), args, 0, static_cast<hipStream_t>(stream));
     }
     const void* f = has_n ? (const void*)k_chain<true> : (const void*)k_chain<false>;
     return (int)hipLaunchKernel(f, dim3(n_slots), dim3(64), args, 0, static_cast<hipStream_t>(stream));
@@ -905,13 +915,14 @@ int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
 // words per block of the direction image: lane major (LANE_WORDS per lane) in the direction-free kernels
 static_assert(DIRFREE_OK<4, 17, false> && DIRFREE_OK<4, 17, true> && DIRFREE_OK<15, 19, false> && DIRFREE_OK<15, 19, true> &&
-                  !DIRFREE_OK<0, 5, false> && !DIRFREE_OK<0, 5, true> && !DIRFREE_OK<-1, 17, true> && !DIRFREE_OK<-1, 9, true>,
+                  DIRFREE_OK<0, 5, false> == (GAMDP_DF5 != 0) && DIRFREE_OK<0, 5, true> == (GAMDP_DF5 != 0) && !DIRFREE_OK<-1, 17, true> && !DIRFREE_OK<-1, 9, true> && !DIRFREE_OK<-1, 5, true>,
               "kernel_dir_block_words() below lists the direction-free kernels by id: keep it in step with DIRFREE_OK");
 int kernel_dir_block_words(int kid)
 {
     switch (kid) {
     case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: return IMG_WORDS<17, true>;
     case K_Q19_CE15: case K_Q19_CE15_N: case K_O19_CE15: return IMG_WORDS<19, true>;
+    case K_C5_CE0: case K_C5_CE0_N: return IMG_WORDS<5, DIRFREE_OK<0, 5, false>>;
     default: return kernel_cols(kid) * 64;
     }
 }
@@ -920,6 +931,15 @@ int kernel_ckpt_words(int kid)
     if (kid == K_P17_CE4) return (int)PairFmt<17, 64>::CK_WORDS;
     if (kid == K_O19_CE15) return (int)PairFmt<19, QL>::CK_WORDS;
     return kernel_dir_block_words(kid);
+}
+
+bool kernel_dirfree(int kid)
+{
+    switch (kid) {
+    case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: case K_O19_CE15: case K_Q19_CE15: case K_Q19_CE15_N: return true;
+    case K_C5_CE0: case K_C5_CE0_N: return GAMDP_DF5 != 0;
+    default: return false;
+    }
 }
 
 int kernel_vimg_words(int kid)

@@ -397,7 +397,19 @@ struct ChainRun {
         if (!ok) { c->set_error(std::string("chain kernel: ") + hipGetErrorString(hipGetLastError())); return GAMDP_EHIP; }
         *ms = k; *from_ref_ms = f;
         c->kernel_ms += k; c->kernel_launches++;
-        if (diag().timing) std::fprintf(stderr, "gamdp chain: kernel %.3f ms, launched %.3f ms after the call began\n", k, f);
+        if (diag().timing) {
+            std::fprintf(stderr, "gamdp chain: kernel %.3f ms, launched %.3f ms after the call began\n", k, f);
+            // the chains that ended last (the device's 100 MHz clock, relative to the first workgroup's start)
+            std::vector<u32> idx(n_mb);
+            u32 t0 = hout[0].t_begin;
+            for (size_t q = 0; q < n_mb; q++) { idx[q] = (u32)q; if ((int32_t)(hout[q].t_begin - t0) < 0) t0 = hout[q].t_begin; }
+            std::sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return (int32_t)(hout[a].t_end - hout[b].t_end) > 0; });
+            for (size_t i = 0; i < std::min<size_t>(6, n_mb); i++) {
+                const u32 q = idx[i];
+                std::fprintf(stderr, "gamdp chain: #%u ended at %.3f ms (began %.3f): %u blocks, %u rows, %u calls, has_n %u, state 0x%x\n", q, (hout[q].t_end - t0) * 1e-5,
+                             (hout[q].t_begin - t0) * 1e-5, hmb[q].n_blocks, hmb[q].rows, hout[q].n_dp, hmb[q].has_n, hout[q].state);
+            }
+        }
         return 0;
     }
     // diagnostics build: the progress markers of the chains
@@ -520,11 +532,15 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     const u64 Y = 2ull * band + 1, LE = (Y - 1) / 5, nblk = ((u64)max_sl - 1 + LE) / 16 + 1;
     const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
     const u32 ypad = (u32)(((2 * band + 2 + 63) / 64) * 64);
-    const u64 slotw = dirw + 4ull * ypad;
+    // direction-free fast blocks (one live row per 4 blocks, the boundary values of every 4th lane per block) when the kernel has them
+    static const bool no_df5 = std::getenv("GAMDP_NO_DF5") != nullptr;
+    const bool df = kernel_dirfree(K_C5_CE0_N) && !no_df5;
+    const u64 ckptw = df ? (nblk / 4 + 2) * (u64)kernel_ckpt_words(K_C5_CE0_N) : 0, bndw = df ? (nblk + 4) * (u64)kernel_bnd_words(K_C5_CE0_N) : 0;
+    const u64 slotw = dirw + 4ull * ypad + ckptw + bndw;
     // k_chain2: two wavefronts and two slots per merge block (one call is walked while the next is filled); GAMDP_L1_ONE_WAVE=1
     // keeps the one-wavefront kernel (A/B)
     static const bool one_wave = std::getenv("GAMDP_L1_ONE_WAVE") != nullptr;
-    const u64 per_wg = one_wave ? 1 : 2;
+    const u64 per_wg = one_wave ? 1 : (u64)chain_slots_per_workgroup();
     const u64 fit = arena / (per_wg * slotw * sizeof(u32));
     if (fit == 0) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
     const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // workgroups per launch: each owns its slot(s)
@@ -538,6 +554,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     cp.mbs = (const DevMB*)(d + off_mb); cp.blks = (const DevBlk*)(d + off_blk); cp.n_mbs = (u32)n_mb;
     cp.cursor = nullptr; cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
     cp.scratch = c->d_chain_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
+    cp.ckpt_off = df ? dirw + 4ull * ypad : 0; cp.bnd_off = cp.ckpt_off + ckptw;
     cp.max_rows = (u32)std::min<u64>(std::max<u64>(1, w[order[0]]), 0x7fffffffu);
     cp.host_out = (ChainOut*)(dm + mo_out); cp.host_done = (u32*)(dm + mo_done); cp.host_audit = (DevResult*)(dm + mo_aud);
     cp.epoch = c->chain_epoch;

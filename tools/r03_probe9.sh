@@ -1,0 +1,9 @@
+# round 3, probe 9: what holds a lone direction-free band-150 wavefront back (timing only: the variants' results are unusable)
+for lib in diag diag_nostore diag_noaread diag_noboth; do
+  GAMDP_LIB=$PWD/gam_ngs_amd/libgamdp_$lib.so GAMDP_DIAG_SKIP_TRACEBACK=1 timeout -s KILL 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --no-proxy --band 150 --pairs 256 2>&1 | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$lib fill only: kernel_ms %.3f'%d['roofline']['kernel_ms_per_launch'])
+"
+done
