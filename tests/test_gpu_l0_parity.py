@@ -126,6 +126,33 @@ def test_medium_pairs_all_kernel_variants():
         assert r.key() == o.key() and r.ops == (ops if f else None), (cs["band"], len(cs["a"]))
 
 
+def test_batches_with_a_small_scratch_arena():
+    """gamdp_ctx_set_arena_bytes: with 16 MB a batch of 36 calls of 2 - 6 kb goes through in many launches of a few slots each
+    (long calls peeled off into launches of their own), and the results are the same as with the whole HBM; with 64 KB not one
+    task fits and the call fails loudly instead of running anything."""
+    from _gpu import ctx
+    rng = random.Random(31)
+    cases = []
+    for k in range(36):
+        n = rng.randrange(2000, 6000)
+        band = (150, 512, 64, 150)[k % 4]
+        a, b = _cases.related_pair(rng, n, n_frac=0.01 if k % 5 == 0 else 0.0)
+        cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False))
+    c = ctx()
+    try:
+        c.set_arena_bytes(16 << 20)
+        res = run_cases(cases, False)
+        c.set_arena_bytes(64 << 10)
+        with pytest.raises(gam.GamdpError, match="arena"):
+            run_cases(cases[:4], False)
+    finally:
+        c.set_arena_bytes(0)
+    for cs, r in zip(cases, res):
+        o, _ = oracle_for(cs, False)
+        assert r.key() == o.key(), (cs["band"], len(cs["a"]), r.key(), o.key())
+    assert [r.key() for r in run_cases(cases, False)] == [r.key() for r in res]   # (and the context is back on its automatic budget)
+
+
 def test_golden_large_synthetic_pairs():
     """50 kb pairs at band 150 / 512 from the benchmark generator; expected values come from the reference."""
     c = ctx()

@@ -20,10 +20,7 @@ def make_mbs(scs):
     return [gam.MergeBlock(i, i, [gam.Block(*b) for b in sc["blocks"]], *sc["tails"]) for i, sc in enumerate(scs)]
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_merge_blocks_match_oracle(seed):
-    c = ctx()
-    scs = _l1cases.scenarios(500 + seed, 60)
+def _check_against_oracle(c, scs):
     masters = gam.SequenceSet(c, [sc["master"].encode() for sc in scs])
     slaves = gam.SequenceSet(c, [sc["slave"].encode() for sc in scs])
     mbs = make_mbs(scs)
@@ -42,8 +39,29 @@ def test_merge_blocks_match_oracle(seed):
         stats["rev"] += mb.align_ok and mb.align_rev
         stats["bad"] += not mb.align_ok
         stats["tails"] += mb.align_ok and mb.n_dp > len(sc["blocks"])
+    return stats
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_merge_blocks_match_oracle(seed):
+    stats = _check_against_oracle(ctx(), _l1cases.scenarios(500 + seed, 60))
     # the generator must exercise every branch of the driver
     assert stats["ok"] >= 15 and stats["rev"] >= 3 and stats["bad"] >= 5 and stats["tails"] >= 5, stats
+
+
+@pytest.mark.parametrize("arena_kb", [24576, 2048, 700])
+def test_merge_blocks_with_a_small_scratch_arena(arena_kb):
+    """gamdp_ctx_set_arena_bytes bounds what a call may claim for scratch.  Half of it goes to the chain launch (three scratch
+    slots of ~133 KB per merge block here): with 24 MB the launch takes the 60 merge blocks in two pieces, with 2 MB two at a
+    time, and with 700 KB not even one workgroup fits and the call falls back to the round loop, a few calls per launch --
+    whatever the path, the results are the oracle's."""
+    c = gam.Context(0)
+    c.set_arena_bytes(arena_kb << 10)
+    try:
+        stats = _check_against_oracle(c, _l1cases.scenarios(503, 60))
+    finally:
+        c.set_arena_bytes(0)
+    assert stats["ok"] >= 15 and stats["bad"] >= 5, stats
 
 
 def test_single_merge_block_calls_match_batched():
