@@ -1,0 +1,12 @@
+# A/B on one box: diagnostics builds with the packed stream before / after the reordering (alternating, two passes)
+B="timeout -s KILL 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --no-proxy"
+for pass in 1 2; do
+for lib in diag_oldpair diag; do
+for P in 100000 12500 4096; do
+ GAMDP_LIB=$PWD/gam_ngs_amd/libgamdp_$lib.so $B --pairs $P 2>&1 | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('%-14s pairs %6d gcups %.0f kernel_ms %.2f'%('$lib', $P, d['value'], d['roofline']['kernel_ms_per_launch']))
+"
+done; done; done
