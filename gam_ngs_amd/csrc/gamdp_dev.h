@@ -185,10 +185,19 @@ struct DevMB {
     u32 try_rev;                   // orientation of the first attempt
     u32 has_n;                     // one of its two contigs holds an N: the chain runs the N-aware cells (12% slower)
 };
-struct ChainOut { u32 n_dp; u32 state; u32 t_begin, t_end; };   // t_*: the device's 100 MHz clock (low word) when the chain's workgroup started / ended (timing diagnostics)
+struct ChainOut { u32 n_dp; u32 state; u32 t_begin, t_end; u32 hw, hw_twin; u32 t_end_att[2]; u32 t_begin2; u32 pad; };   // t_*: the device's 100 MHz clock (low word) when the chain's workgroup started / ended (timing diagnostics)
 //   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
+// A long chain gets a twin: a second workgroup that runs the OTHER orientation (findBestAlignment's second attempt, :1463-1509)
+// at the same time instead of after the first has failed -- the merge blocks that need it (a first guess that was wrong, a merge
+// block that fails) are the ones a call waits for.  The two never wait for each other: each leaves its verdict here, and the one
+// that finishes second puts the chain's record list together (attempt 0's records, then attempt 1's if attempt 0 failed --
+// exactly where the one-after-the-other chain puts them) and hands it to the host.  A first attempt that settles the chain
+// raises `cancel`; the twin looks at it between calls.
+struct ChainSync { u32 verdict[2]; u32 n[2]; u32 fin; u32 cancel; u32 t_begin; u32 hw[2]; u32 t_end[2]; u32 t_begin2; };   // verdict: ChainOut::state of that attempt alone (1 = failed)
 struct ChainParams {
     const DevMB* mbs; const DevBlk* blks; u32 n_mbs;
+    u32 n_twins;                   // the launch's first n_twins workgroups are the twins of merge blocks 0 .. n_twins - 1 (only in a launch that takes all merge blocks at once)
+    ChainSync* sync;               // [n_twins], zeroed before the launch
     u32 first_mb;                  // the launch takes merge blocks first_mb .. first_mb + grid - 1
     u32* cursor;
     DevResult* audit; ChainOut* out;

@@ -111,6 +111,7 @@ __device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams&
         }
     }
     for (int blk = 0; blk < nblk;) {
+        if (cancelled(t.cancel)) break;
         const int m = mode_of(blk);
         if (m == M_FAST) {
             int e = blk + 1;
@@ -144,6 +145,7 @@ template <int C, int CE, bool HASN>
 __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& p, u32* slot, const int lane, const bool lrpt)
 {
     Tk t;
+    t.cancel = nullptr;
     fill_task<C, CE, HASN>(dt, p, slot, lane, lrpt, t);
     if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);   // end cell + walk: few vector instructions, whoever still fills goes first
     finish_task<C, CE, HASN>(&t, &dt, &p, lane);
@@ -182,6 +184,7 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
     t.vimg = (gptr)(slot + p.val_off + (u64)task_in_wave * 2u * vimg_words);
     t.df_lo = t.df_hi = 0;
     t.prio_R = t.prio_nblk = 0;
+    t.cancel = nullptr;
     const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
     t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
     const bool ge = t.end_a >= (int64_t)t.begin_a + t.band;
@@ -278,6 +281,7 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
     t.dir = rlp(m.dir, src); t.h0row = rlp(m.h0row, src); t.pos0 = rlp(m.pos0, src); t.lastrow = rlp(m.lastrow, src); t.adh = rlp(m.adh, src);
     t.ckpt = rlp(m.ckpt, src); t.bnd = rlp(m.bnd, src);
     t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src);
+    t.prio_R = t.prio_nblk = 0; t.cancel = nullptr;
     return t;
 }
 
@@ -441,6 +445,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     const int nblk = (X - 1 + LE) / ROWS + 1;      // of this lane's task
     const int nblk_max = quad_max(nblk);
     t.prio_R = (p.prio_R != 0 && qi >= p.prio_from) ? (int)p.prio_R : 0; t.prio_nblk = nblk_max;
+    t.cancel = nullptr;
     if (t.prio_R != 0) set_prio_by_remaining(nblk_max, t.prio_R);
     BlockState<C> st;
     init_row0<C, HASN, true, LPT>(&st, &t, lane);
@@ -600,6 +605,7 @@ template <bool HASN>
 __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slot, const int lane)
 {
     const u32 t_begin = (u32)wall_clock64();
+    const u32 hw_me = ((u32)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | ((u32)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu), hw_other = 0, te0 = 0, te1 = 0, tb2 = 0;   // XCC_ID | HW_ID (timing diagnostics)
     const DevMB* mb = unip(cp.mbs + mi);
     const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
@@ -689,7 +695,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         try_rev = !try_rev;
     }
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.out[mi] = o; }
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.out[mi] = o; }
     // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
@@ -697,7 +703,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
         const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
         for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
-        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.host_out[mi] = o; }
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
@@ -731,21 +737,25 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
 // call of a chain needs one thing from the walk of this one: the last match (PctgBuilder.cc:1660-1667), which is the FIRST match
 // the walk meets.  So the workgroup has two wavefronts and two scratch slots: wavefront 0 fills call k + 1 into one slot while
 // wavefront 1 walks call k in the other (ChainMail, kernel_finish.inc).  Same calls, same records, same order in the audit list.
+// role: 0 = the whole chain (both attempts, one after the other), 1 = the first attempt of a chain that has a twin, 2 = the twin
 template <bool HASN>
-__device__ __forceinline__ void chain_filler(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slots, const int lane)
+__device__ __forceinline__ void chain_filler(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slots, const int lane, const int role)
 {
-    const u32 t_begin = (u32)wall_clock64();
+    u32 t_begin = (u32)wall_clock64();
+    u32 hw_me = ((u32)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | ((u32)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu), hw_other = 0, te0 = 0, te1 = 0, tb2 = 0;   // XCC_ID | HW_ID (timing diagnostics)
     const DevMB* mb = unip(cp.mbs + mi);
     const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
     const u64 align_thr = (u64)uni64((int64_t)mb->align_thr);
     const u32 first_blk = (u32)uni((int)mb->first_blk), n = (u32)uni((int)mb->n_blocks), audit_first = (u32)uni((int)mb->audit_first);
     const u32 band = cp.band;
-    bool try_rev = uni((int)mb->try_rev) != 0;
+    bool try_rev = (uni((int)mb->try_rev) != 0) != (role == 2);
     auto frame_len = [](const int32_t b, const int32_t e) -> int32_t { return e < b ? 0 : e - b + 1; };   // Frame.cc:124-127
-    u32 n_dp = 0, state = 1;
+    ChainSync* const sy = role != 0 ? cp.sync + mi : nullptr;
+    if (role == 1 && lane == 0) sy->t_begin = t_begin;
+    u32 n_dp = role == 2 ? n : 0u, state = 1;   // (a second attempt follows a first that made all its n calls)
     int sent = 0;   // calls handed to the walker so far (the chain's calls that need a DP)
-    for (int attempt = 0;; ) {
+    for (int attempt = role == 2 ? 1 : 0;; ) {
         int64_t cur_ms = (int64_t)m_start;
         int64_t cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);   // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
         u64 last_a = 0, last_b = 0;
@@ -753,7 +763,9 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         int rows_left = uni((int)mb->rows);
         // (the walkers are idle here: every call handed over so far is done)
         if (lane == 0) { s_mail.bad = 0; s_mail.sum = 0; }
+        bool cancelled = false;
         for (u32 k = 0; k < n; ++k) {
+            if (role == 2 && uni((int)__hip_atomic_load(&sy->cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) { cancelled = true; break; }   // the first attempt has settled the chain
             const DevBlk* bk = unip(cp.blks + first_blk + k);
             const int32_t cm_b = uni(bk->m_begin), cm_e = uni(bk->m_end), cs_b = uni(bk->s_begin), cs_e = uni(bk->s_end);
             const int32_t ml = frame_len(cm_b, cm_e), sl = frame_len(cs_b, cs_e);
@@ -793,6 +805,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
                 dt.X = (int32_t)X; dt.band = (int32_t)band;
                 dt.flags = 0; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
                 Tk t;
+                t.cancel = role == 2 ? &sy->cancel : nullptr;
                 fill_task<5, 0, HASN>(dt, p, slots + (u64)par * cp.slot_words, lane, false, t);
                 if (lane == 0) { s_mail.tk[par] = t; s_mail.dt[par] = dt; }
                 ++sent;
@@ -809,15 +822,43 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         mail_wait_ge(&s_mail.n_done, sent);   // every walk of this attempt has ended: is_good(vector), :1711-1724
         const bool all_good = !settled_bad && uni(s_mail.bad) == 0;
         const u64 sumlen = (u64)uni64((int64_t)s_mail.sum);
+        if (cancelled) { state = 1; break; }   // (whatever: nobody looks at a cancelled twin's verdict)
         if (thrown) { state = 2; break; }
         if (all_good && sumlen >= align_thr) { state = try_rev ? 0x100u : 0u; break; }
-        if (++attempt == 2) { state = 1; break; }                                          // :1512
+        if (++attempt == 2 || role == 1) { state = 1; break; }                             // :1512 (role 1: the second attempt is the twin's)
         try_rev = !try_rev;
     }
     if (lane == 0) { s_mail.total = sent; s_mail.quit = 1; }
     mail_post(&s_mail.filled, sent + CH_NW, lane);   // (wakes every walker, whichever call it waits for; nothing behind those counts)
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.out[mi] = o; }
+    if (role != 0) {
+        // the verdict of this attempt; whoever is second puts the chain together
+        const int me = role - 1;
+        if (lane == 0) {
+            sy->verdict[me] = state; sy->n[me] = n_dp;
+            sy->hw[me] = hw_me; sy->t_end[me] = (u32)wall_clock64(); if (role == 2) sy->t_begin2 = t_begin;
+            if (role == 1 && state != 1u) __hip_atomic_store(&sy->cancel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        u32 before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(&sy->fin, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // (release: this attempt's records and verdict; acquire: the other's)
+        before = (u32)__builtin_amdgcn_readfirstlane((int)before);
+        // a first attempt that settles the chain hands it over at once (the twin is winding down and never does); one that
+        // fails leaves it to whoever is second
+        const bool mine = role == 1 ? (state != 1u || before != 0u) : (before != 0u && (u32)uni((int)__hip_atomic_load(&sy->verdict[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1u);
+        if (!mine) {
+            if (role == 2 && lane == 0) { cp.host_out[mi].t_begin2 = t_begin; cp.host_out[mi].t_end_att[1] = (u32)wall_clock64(); }   // (timing diagnostics: a twin that wound down after the chain was handed over)
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const u32 v0 = (u32)uni((int)sy->verdict[0]), n0 = (u32)uni((int)sy->n[0]), v1 = (u32)uni((int)sy->verdict[1]), n1 = (u32)uni((int)sy->n[1]);
+        if (v0 != 1u) { state = v0; n_dp = n0; }   // the first attempt settled the chain (good, or a call threw)
+        else { state = v1; n_dp = n1; }             // it failed after all its n calls: the second attempt's records follow them
+        t_begin = (u32)uni((int)sy->t_begin);
+        hw_me = (u32)uni((int)sy->hw[0]); hw_other = (u32)uni((int)sy->hw[1]);
+        te0 = (u32)uni((int)sy->t_end[0]); te1 = (u32)uni((int)sy->t_end[1]); tb2 = (u32)uni((int)sy->t_begin2);
+    }
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.out[mi] = o; }
     // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
@@ -825,7 +866,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
         const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
         for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
-        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); cp.host_out[mi] = o; }
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
@@ -855,7 +896,9 @@ __global__ __launch_bounds__(64 * (1 + CH_NW), GAMDP_WAVES_PER_SIMD) void k_chai
 {
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
-    const u32 mi = cp.first_mb + blockIdx.x;
+    const bool twin = blockIdx.x < cp.n_twins;
+    const u32 mi = twin ? blockIdx.x : cp.first_mb + blockIdx.x - cp.n_twins;
+    const int role = twin ? 2 : (mi < cp.n_twins ? 1 : 0);
     u32* slots = cp.scratch + (u64)blockIdx.x * (u64)CH_NS * cp.slot_words;
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
@@ -869,9 +912,9 @@ __global__ __launch_bounds__(64 * (1 + CH_NW), GAMDP_WAVES_PER_SIMD) void k_chai
     const bool mb_n = HASN && uni((int)cp.mbs[mi].has_n) != 0;
     if (wave == 0) {
         if constexpr (HASN) {
-            if (mb_n) chain_filler<true>(cp, p, mi, slots, lane);
-            else chain_filler<false>(cp, p, mi, slots, lane);
-        } else chain_filler<false>(cp, p, mi, slots, lane);
+            if (mb_n) chain_filler<true>(cp, p, mi, slots, lane, role);
+            else chain_filler<false>(cp, p, mi, slots, lane, role);
+        } else chain_filler<false>(cp, p, mi, slots, lane, role);
     } else {
         if constexpr (HASN) {
             if (mb_n) chain_walker<true>(p, lane);

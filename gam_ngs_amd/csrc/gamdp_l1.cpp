@@ -404,10 +404,18 @@ struct ChainRun {
             u32 t0 = hout[0].t_begin;
             for (size_t q = 0; q < n_mb; q++) { idx[q] = (u32)q; if ((int32_t)(hout[q].t_begin - t0) < 0) t0 = hout[q].t_begin; }
             std::sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return (int32_t)(hout[a].t_end - hout[b].t_end) > 0; });
+            {   // the twin that ended last
+                size_t qm = 0; int32_t lm = -1;
+                for (size_t q = 0; q < n_mb; q++) if (hout[q].t_end_att[1] && (int32_t)(hout[q].t_end_att[1] - t0) > lm) { lm = (int32_t)(hout[q].t_end_att[1] - t0); qm = q; }
+                if (lm >= 0) std::fprintf(stderr, "gamdp chain: last twin to end: #%zu's, at %.3f ms (its chain was handed over at %.3f)\n", qm, lm * 1e-5, (hout[qm].t_end - t0) * 1e-5);
+            }
             for (size_t i = 0; i < std::min<size_t>(6, n_mb); i++) {
                 const u32 q = idx[i];
                 std::fprintf(stderr, "gamdp chain: #%u ended at %.3f ms (began %.3f): %u blocks, %u rows, %u calls, has_n %u, state 0x%x\n", q, (hout[q].t_end - t0) * 1e-5,
                              (hout[q].t_begin - t0) * 1e-5, hmb[q].n_blocks, hmb[q].rows, hout[q].n_dp, hmb[q].has_n, hout[q].state);
+                auto place = [](u32 h) { char b[64]; std::snprintf(b, sizeof b, "xcc %u se %u sh %u cu %u simd %u", h >> 16, (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15, (h >> 4) & 3); return std::string(b); };
+                if (hout[q].t_end_att[1]) std::fprintf(stderr, "gamdp chain:     first attempt ended at %.3f ms, the twin began at %.3f and ended at %.3f ms\n", (hout[q].t_end_att[0] - t0) * 1e-5, (hout[q].t_begin2 - t0) * 1e-5, (hout[q].t_end_att[1] - t0) * 1e-5);
+                std::fprintf(stderr, "gamdp chain:     filler on %s%s%s\n", place(hout[q].hw).c_str(), hout[q].hw_twin ? "; twin's on " : "", hout[q].hw_twin ? place(hout[q].hw_twin).c_str() : "");
             }
         }
         return 0;
@@ -463,7 +471,14 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     // mirror: ChainOut[] | done flags | DevResult audit[]               (pinned, coherent; written by the chains as they end)
     const u64 n_mb = act.size(), n_audit = 2 * n_blk;
     auto up = [](u64 v) { return (v + 255) & ~255ull; };
-    const u64 off_mb = 0, off_blk = up(off_mb + n_mb * sizeof(DevMB)), off_out = up(off_blk + n_blk * sizeof(DevBlk)),
+    // the longest chains get a twin workgroup for their second orientation (ChainSync, gamdp_dev.h): those within 1/8 of the
+    // longest, at most 256 of them; GAMDP_L1_NO_TWINS=1: none
+    static const bool no_twins = std::getenv("GAMDP_L1_NO_TWINS") != nullptr;
+    u64 n_tw = 0;
+    const u64 tw_cap = n_mb < 256 ? std::max<u64>(16, 256 - n_mb) : 256;   // (a small call: one workgroup per CU as long as that leaves room for a few)
+    if (!no_twins)
+        while (n_tw < n_mb && n_tw < tw_cap && w[order[n_tw]] * 8 >= w[order[0]] && w[order[n_tw]] >= 1024) n_tw++;
+    const u64 off_mb = 0, off_blk = up(off_mb + n_mb * sizeof(DevMB)), off_sync = up(off_blk + n_blk * sizeof(DevBlk)), off_out = up(off_sync + (n_tw + 1) * sizeof(ChainSync)),
               off_aud = up(off_out + n_mb * sizeof(ChainOut)), total = up(off_aud + n_audit * sizeof(DevResult));
     const u64 mo_out = 0, mo_done = up(mo_out + n_mb * sizeof(ChainOut)), mo_aud = up(mo_done + n_mb * sizeof(u32)), mtotal = up(mo_aud + n_audit * sizeof(DevResult));
     if (total > c->cap_chain) {
@@ -543,8 +558,9 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     const u64 per_wg = one_wave ? 1 : (u64)chain_slots_per_workgroup();
     const u64 fit = arena / (per_wg * slotw * sizeof(u32));
     if (fit == 0) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
-    const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // workgroups per launch: each owns its slot(s)
-    const u64 need_scratch = per_wg * slotw * n_slots;
+    if (one_wave || fit < n_mb + n_tw) n_tw = 0;   // (twins only in a launch that takes every merge block at once)
+    const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // merge blocks per launch: each workgroup owns its slot(s)
+    const u64 need_scratch = per_wg * slotw * (n_slots + n_tw);
     if (need_scratch > c->cap_chain_scratch) {
         if (c->d_chain_scratch) { (void)hipFree(c->d_chain_scratch); c->d_chain_scratch = nullptr; c->cap_chain_scratch = 0; }
         if (hipMalloc(&c->d_chain_scratch, need_scratch * sizeof(u32)) != hipSuccess) { c->d_chain_scratch = nullptr; c->set_error("hipMalloc of the chains' scratch slots failed"); return GAMDP_ENOMEM; }
@@ -552,6 +568,8 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     }
     ChainParams cp;
     cp.mbs = (const DevMB*)(d + off_mb); cp.blks = (const DevBlk*)(d + off_blk); cp.n_mbs = (u32)n_mb;
+    cp.n_twins = (u32)n_tw; cp.sync = (ChainSync*)(d + off_sync);
+    std::memset(h + off_sync, 0, (n_tw + 1) * sizeof(ChainSync));
     cp.cursor = nullptr; cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
     cp.scratch = c->d_chain_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
     cp.ckpt_off = df ? dirw + 4ull * ypad : 0; cp.bnd_off = cp.ckpt_off + ckptw;
@@ -561,7 +579,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     cp.two_waves = one_wave ? 0u : 1u;
     if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
-    if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (int)has_n);
+    if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, %llu twins, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (unsigned long long)n_tw, (int)has_n);
     run.n_mb = n_mb; run.band = band; run.hmb = hmb;
     run.hout = (const ChainOut*)(hm + mo_out); run.done = (const volatile u32*)(hm + mo_done); run.haud = (const DevResult*)(hm + mo_aud);
     run.epoch = cp.epoch; run.stream = c->chain_stream; run.dout = cp.out;
@@ -570,7 +588,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     ok = ok && hipEventRecord(run.e0, c->chain_stream) == hipSuccess;
     for (u64 first = 0; ok && first < n_mb; first += n_slots) {   // (one launch unless the arena holds fewer slots than there are merge blocks)
         cp.first_mb = (u32)first;
-        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)std::min<u64>(n_slots, n_mb - first), c->chain_stream) == 0;
+        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)(std::min<u64>(n_slots, n_mb - first) + n_tw), c->chain_stream) == 0;
     }
     ok = ok && hipEventRecord(run.e1, c->chain_stream) == hipSuccess;
     if (!ok) {

@@ -189,15 +189,16 @@ def test_standalone_tool_through_to_gam_fasta(tmp_path):
                                                                       ["s%d" % i for i in range(len(scs))])
 
 
-@pytest.mark.parametrize("switch", ["GAMDP_L1_ROUNDS", "GAMDP_L1_ONE_WAVE"])
+@pytest.mark.parametrize("switch", ["GAMDP_L1_ROUNDS", "GAMDP_L1_ONE_WAVE", "GAMDP_L1_NO_TWINS"])
 def test_other_ways_through_a_merge_block_call_in_a_fresh_process(switch):
     """The main chains of the merge blocks run on the device in one launch -- a workgroup per merge block, one wavefront filling
-    and two walking (k_chain2) -- and the host replays its state machines over the records.  GAMDP_L1_ONE_WAVE=1 keeps the
-    one-wavefront chain kernel (k_chain), GAMDP_L1_ROUNDS=1 every call in the round loop (what other bands than 150 take
-    anyway).  All three must give what the oracle gives: the merge-block tests of this file and the GAGE-shaped ones once more
+    and two walking (k_chain2), the long chains with a twin workgroup that runs the other orientation at the same time -- and
+    the host replays its state machines over the records.  GAMDP_L1_NO_TWINS=1 runs the two orientations one after the other,
+    GAMDP_L1_ONE_WAVE=1 keeps the one-wavefront chain kernel (k_chain), GAMDP_L1_ROUNDS=1 every call in the round loop (what
+    other bands than 150 take anyway).  All of them must give what the oracle gives: the merge-block tests of this file and the GAGE-shaped ones once more
     in a child per switch (the switches are read once per process)."""
     import os, subprocess, sys
-    if os.environ.get("GAMDP_L1_ROUNDS") or os.environ.get("GAMDP_L1_ONE_WAVE"):
+    if os.environ.get("GAMDP_L1_ROUNDS") or os.environ.get("GAMDP_L1_ONE_WAVE") or os.environ.get("GAMDP_L1_NO_TWINS"):
         pytest.skip("already inside the child")
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, **{switch: "1"})
