@@ -1,4 +1,6 @@
-# A/B on one box: diagnostics builds with the packed stream before / after the reordering (alternating, two passes)
+# A/B on one box: diagnostics builds with the packed stream before / after the reordering (alternating, two passes).
+# libgamdp_diag_oldpair.so = `make -C gam_ngs_amd/csrc variant NAME=oldpair` with kernel_pair.inc of the commit before (not kept in the tree).
+# Result: no difference beyond noise (13 105 - 13 116 / 10 430 - 10 820 / 10 440 - 10 500 GCUPS at 100 000 / 12 500 / 4 096 pairs, both).
 B="timeout -s KILL 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --no-proxy"
 for pass in 1 2; do
 for lib in diag_oldpair diag; do
