@@ -184,6 +184,11 @@ struct DevMB {
     u32 rows;                      // sum of its slave frames: the rows one pass of the chain fills
     u32 try_rev;                   // orientation of the first attempt
     u32 has_n;                     // one of its two contigs holds an N: the chain runs the N-aware cells (12% slower)
+    // its scratch: slots sized for ITS longest call (x_size <= its longest slave frame), not the launch's
+    u32 pad0;
+    u64 slot_off[2];               // word offset in ChainParams::scratch of the first slot of its workgroup / of its twin's (within the piece of the launch it is in)
+    u64 slot_words, dir_words;     // words per slot; direction words at the start of a slot (side buffers follow)
+    u64 ckpt_off, bnd_off;         // as in LaunchParams (0 = directions everywhere)
 };
 struct ChainOut { u32 n_dp; u32 state; u32 t_begin, t_end; u32 hw, hw_twin; u32 t_end_att[2]; u32 t_begin2; u32 pad; };   // t_*: the device's 100 MHz clock (low word) when the chain's workgroup started / ended (timing diagnostics)
 //   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
@@ -201,8 +206,7 @@ struct ChainParams {
     u32 first_mb;                  // the launch takes merge blocks first_mb .. first_mb + grid - 1
     u32* cursor;
     DevResult* audit; ChainOut* out;
-    u32* scratch; u64 slot_words, dir_words; u32 ypad; u32 band;
-    u64 ckpt_off, bnd_off;         // word offsets inside a slot of the direction-free fill's stores (0 = directions everywhere), as in LaunchParams
+    u32* scratch; u32 ypad; u32 band;   // (slot geometry: per merge block, DevMB)
     u32 max_rows;                  // the largest DevMB::rows of the call: chains with many rows left go first (set_prio_by_remaining)
     // the host's view while the launch runs (pinned, coherent host memory, device pointers): a chain that ends copies its
     // records and its ChainOut there and then raises its flag (done[mi] = epoch, system-scope release), so the host takes a

@@ -720,11 +720,12 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
 {
     const int lane = threadIdx.x;
     const u32 mi = cp.first_mb + blockIdx.x;
-    u32* slot = cp.scratch + (u64)blockIdx.x * cp.slot_words;
+    const DevMB* const mbp = unip(cp.mbs + mi);
+    u32* slot = cp.scratch + (u64)uni64((int64_t)mbp->slot_off[0]);
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
-    p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
-    p.ckpt_off = cp.ckpt_off; p.bnd_off = cp.bnd_off; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.scratch = cp.scratch; p.slot_words = (u64)uni64((int64_t)mbp->slot_words); p.dir_words = (u64)uni64((int64_t)mbp->dir_words); p.ypad = cp.ypad;
+    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
     if constexpr (HASN) {
         if (uni((int)cp.mbs[mi].has_n) != 0) run_chain<true>(cp, p, mi, slot, lane);
         else run_chain<false>(cp, p, mi, slot, lane);
@@ -806,7 +807,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
                 dt.flags = 0; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
                 Tk t;
                 t.cancel = role == 2 ? &sy->cancel : nullptr;
-                fill_task<5, 0, HASN>(dt, p, slots + (u64)par * cp.slot_words, lane, false, t);
+                fill_task<5, 0, HASN>(dt, p, slots + (u64)par * p.slot_words, lane, false, t);
                 if (lane == 0) { s_mail.tk[par] = t; s_mail.dt[par] = dt; }
                 ++sent;
                 mail_post(&s_mail.filled, sent, lane);   // (after the wavefront's stores: rows, directions, side buffers)
@@ -899,11 +900,12 @@ __global__ __launch_bounds__(64 * (1 + CH_NW), GAMDP_WAVES_PER_SIMD) void k_chai
     const bool twin = blockIdx.x < cp.n_twins;
     const u32 mi = twin ? blockIdx.x : cp.first_mb + blockIdx.x - cp.n_twins;
     const int role = twin ? 2 : (mi < cp.n_twins ? 1 : 0);
-    u32* slots = cp.scratch + (u64)blockIdx.x * (u64)CH_NS * cp.slot_words;
+    const DevMB* const mbp = unip(cp.mbs + mi);
+    u32* slots = cp.scratch + (u64)uni64((int64_t)mbp->slot_off[twin ? 1 : 0]);
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
-    p.scratch = cp.scratch; p.slot_words = cp.slot_words; p.dir_words = cp.dir_words; p.ypad = cp.ypad;
-    p.ckpt_off = cp.ckpt_off; p.bnd_off = cp.bnd_off; p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.scratch = cp.scratch; p.slot_words = (u64)uni64((int64_t)mbp->slot_words); p.dir_words = (u64)uni64((int64_t)mbp->dir_words); p.ypad = cp.ypad;
+    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
     if (threadIdx.x == 0) {
         s_mail.filled = 0; s_mail.quit = 0; s_mail.total = 0; s_mail.claim = 0; s_mail.n_done = 0;
         for (int k = 0; k < CH_NS; ++k) { s_mail.early_of[k] = 0; s_mail.done_of[k] = 0; }

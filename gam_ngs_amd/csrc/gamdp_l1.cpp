@@ -447,7 +447,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     if (act.empty()) return 0;
     // longest chains first
     std::vector<u64> w(act.size(), 0);
-    u32 max_sl = 1;
+    std::vector<u32> longest(act.size(), 1);   // its longest slave frame: no call of the chain has more rows
     u64 n_blk = 0;
     bool has_n = false;
     std::vector<u32> need_rc;
@@ -456,7 +456,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
         for (u32 k = 0; k < in.n_blocks; k++) {
             const int32_t sl = frame_len(in.blocks[k].s_begin, in.blocks[k].s_end);
             w[q] += (u64)sl;
-            max_sl = std::max<u32>(max_sl, (u32)sl);
+            longest[q] = std::max<u32>(longest[q], (u32)sl);
         }
         n_blk += in.n_blocks;
         has_n = has_n || ms->has_n[in.m_id] || ss->has_n[in.s_id];
@@ -543,24 +543,55 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
         }
         blk_at += in.n_blocks;
     }
-    // scratch: one slot per resident wavefront, sized for the longest call any chain can make (x_size <= its slave frame)
-    const u64 Y = 2ull * band + 1, LE = (Y - 1) / 5, nblk = ((u64)max_sl - 1 + LE) / 16 + 1;
-    const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
+    // Scratch: every workgroup goes round its own slots (chain_slots_per_workgroup(); one for the one-wavefront kernel), sized
+    // for the longest call ITS chain can make (x_size <= its longest slave frame) -- a call of a 30 Mb genome has a few chains
+    // with frames of 100 kb and two thousand with frames of a few kb.  What does not fit the arena at once goes in pieces, one
+    // launch after the other over the same memory; twins only when everything fits at once.
+    const u64 Y = 2ull * band + 1, LE = (Y - 1) / 5;
     const u32 ypad = (u32)(((2 * band + 2 + 63) / 64) * 64);
     // direction-free fast blocks (one live row per 4 blocks, the boundary values of every 4th lane per block) when the kernel has them
     static const bool no_df5 = std::getenv("GAMDP_NO_DF5") != nullptr;
     const bool df = kernel_dirfree(K_C5_CE0_N) && !no_df5;
-    const u64 ckptw = df ? (nblk / 4 + 2) * (u64)kernel_ckpt_words(K_C5_CE0_N) : 0, bndw = df ? (nblk + 4) * (u64)kernel_bnd_words(K_C5_CE0_N) : 0;
-    const u64 slotw = dirw + 4ull * ypad + ckptw + bndw;
-    // k_chain2: two wavefronts and two slots per merge block (one call is walked while the next is filled); GAMDP_L1_ONE_WAVE=1
-    // keeps the one-wavefront kernel (A/B)
+    // k_chain2: a filling and two walking wavefronts per merge block; GAMDP_L1_ONE_WAVE=1 keeps the one-wavefront kernel (A/B)
     static const bool one_wave = std::getenv("GAMDP_L1_ONE_WAVE") != nullptr;
     const u64 per_wg = one_wave ? 1 : (u64)chain_slots_per_workgroup();
-    const u64 fit = arena / (per_wg * slotw * sizeof(u32));
-    if (fit == 0) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
-    if (one_wave || fit < n_mb + n_tw) n_tw = 0;   // (twins only in a launch that takes every merge block at once)
-    const u32 n_slots = (u32)std::min<u64>(n_mb, fit);   // merge blocks per launch: each workgroup owns its slot(s)
-    const u64 need_scratch = per_wg * slotw * (n_slots + n_tw);
+    const u64 arena_words = arena / sizeof(u32);
+    u64 words_all = 0, words_twins = 0, slotw_max = 0;
+    for (size_t q = 0; q < n_mb; q++) {
+        DevMB& x = hmb[q];
+        const u64 nblk = ((u64)longest[order[q]] - 1 + LE) / 16 + 1;
+        const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
+        const u64 ckptw = df ? (nblk / 4 + 2) * (u64)kernel_ckpt_words(K_C5_CE0_N) : 0, bndw = df ? (nblk + 4) * (u64)kernel_bnd_words(K_C5_CE0_N) : 0;
+        x.pad0 = 0;
+        x.dir_words = dirw; x.slot_words = dirw + 4ull * ypad + ckptw + bndw;
+        x.ckpt_off = df ? dirw + 4ull * ypad : 0; x.bnd_off = x.ckpt_off + ckptw;
+        slotw_max = std::max(slotw_max, x.slot_words);
+        words_all += per_wg * x.slot_words;
+        if (q < n_tw) words_twins += per_wg * x.slot_words;
+    }
+    if (per_wg * slotw_max > arena_words) return 0;   // (a frame too long for the arena: the round loop peels such calls off by itself)
+    if (one_wave || words_all + words_twins > arena_words) { n_tw = 0; words_twins = 0; }
+    // pieces: [first, first + count) of the list, each within the arena; slot offsets are relative to the piece
+    std::vector<std::pair<u32, u32>> pieces;
+    u64 need_scratch = 0;
+    {
+        u64 at = 0;
+        for (size_t q = 0; q < n_tw; q++) { hmb[q].slot_off[1] = at; at += per_wg * hmb[q].slot_words; }   // (the twins' workgroups come first in the grid)
+        u32 first = 0;
+        for (size_t q = 0; q < n_mb; q++) {
+            const u64 mine = per_wg * hmb[q].slot_words;
+            if (at + mine > arena_words) {   // (never with twins: then everything fits)
+                pieces.emplace_back(first, (u32)q - first);
+                need_scratch = std::max(need_scratch, at);
+                first = (u32)q; at = 0;
+            }
+            hmb[q].slot_off[0] = at;
+            if (q >= n_tw) hmb[q].slot_off[1] = 0;
+            at += mine;
+        }
+        pieces.emplace_back(first, (u32)n_mb - first);
+        need_scratch = std::max(need_scratch, at);
+    }
     if (need_scratch > c->cap_chain_scratch) {
         if (c->d_chain_scratch) { (void)hipFree(c->d_chain_scratch); c->d_chain_scratch = nullptr; c->cap_chain_scratch = 0; }
         if (hipMalloc(&c->d_chain_scratch, need_scratch * sizeof(u32)) != hipSuccess) { c->d_chain_scratch = nullptr; c->set_error("hipMalloc of the chains' scratch slots failed"); return GAMDP_ENOMEM; }
@@ -571,24 +602,23 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     cp.n_twins = (u32)n_tw; cp.sync = (ChainSync*)(d + off_sync);
     std::memset(h + off_sync, 0, (n_tw + 1) * sizeof(ChainSync));
     cp.cursor = nullptr; cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
-    cp.scratch = c->d_chain_scratch; cp.slot_words = slotw; cp.dir_words = dirw; cp.ypad = ypad; cp.band = band;
-    cp.ckpt_off = df ? dirw + 4ull * ypad : 0; cp.bnd_off = cp.ckpt_off + ckptw;
+    cp.scratch = c->d_chain_scratch; cp.ypad = ypad; cp.band = band;
     cp.max_rows = (u32)std::min<u64>(std::max<u64>(1, w[order[0]]), 0x7fffffffu);
     cp.host_out = (ChainOut*)(dm + mo_out); cp.host_done = (u32*)(dm + mo_done); cp.host_audit = (DevResult*)(dm + mo_aud);
     cp.epoch = c->chain_epoch;
     cp.two_waves = one_wave ? 0u : 1u;
     if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
-    if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %u slots of %llu words, %llu twins, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, n_slots, (unsigned long long)slotw, (unsigned long long)n_tw, (int)has_n);
+    if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %zu piece(s), %.1f MB of scratch (slots of up to %llu words), %llu twins, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, pieces.size(), need_scratch * 4e-6, (unsigned long long)slotw_max, (unsigned long long)n_tw, (int)has_n);
     run.n_mb = n_mb; run.band = band; run.hmb = hmb;
     run.hout = (const ChainOut*)(hm + mo_out); run.done = (const volatile u32*)(hm + mo_done); run.haud = (const DevResult*)(hm + mo_aud);
     run.epoch = cp.epoch; run.stream = c->chain_stream; run.dout = cp.out;
     run.t_launch = std::chrono::steady_clock::now();
     bool ok = hipMemcpyAsync(d, h, off_out, hipMemcpyHostToDevice, c->chain_stream) == hipSuccess;
     ok = ok && hipEventRecord(run.e0, c->chain_stream) == hipSuccess;
-    for (u64 first = 0; ok && first < n_mb; first += n_slots) {   // (one launch unless the arena holds fewer slots than there are merge blocks)
-        cp.first_mb = (u32)first;
-        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)(std::min<u64>(n_slots, n_mb - first) + n_tw), c->chain_stream) == 0;
+    for (size_t pc = 0; ok && pc < pieces.size(); pc++) {   // (one launch unless the arena is too small for all the slots at once)
+        cp.first_mb = pieces[pc].first;
+        ok = launch_chain(cp, has_n || diag().force_n, (unsigned)(pieces[pc].second + n_tw), c->chain_stream) == 0;
     }
     ok = ok && hipEventRecord(run.e1, c->chain_stream) == hipSuccess;
     if (!ok) {

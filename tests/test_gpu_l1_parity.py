@@ -49,12 +49,13 @@ def test_merge_blocks_match_oracle(seed):
     assert stats["ok"] >= 15 and stats["rev"] >= 3 and stats["bad"] >= 5 and stats["tails"] >= 5, stats
 
 
-@pytest.mark.parametrize("arena_kb", [24576, 2048, 700])
+@pytest.mark.parametrize("arena_kb", [24576, 6144, 2048, 700])
 def test_merge_blocks_with_a_small_scratch_arena(arena_kb):
-    """gamdp_ctx_set_arena_bytes bounds what a call may claim for scratch.  Half of it goes to the chain launch (three scratch
-    slots of ~133 KB per merge block here): with 24 MB the launch takes the 60 merge blocks in two pieces, with 2 MB two at a
-    time, and with 700 KB not even one workgroup fits and the call falls back to the round loop, a few calls per launch --
-    whatever the path, the results are the oracle's."""
+    """gamdp_ctx_set_arena_bytes bounds what a call may claim for scratch.  Half of it goes to the chain launch (per merge block
+    three scratch slots sized for its own longest frame, up to 133 KB each here, 8 MB in all): with 24 MB the launch takes the
+    60 merge blocks at once, the longest with twin workgroups; with 6 MB and 2 MB in three and eight pieces without twins; and
+    with 700 KB the longest chain's workgroup does not fit at all and the call falls back to the round loop, a few calls per
+    launch -- whatever the path, the results are the oracle's."""
     c = gam.Context(0)
     c.set_arena_bytes(arena_kb << 10)
     try:
