@@ -74,7 +74,6 @@ struct LaunchParams {
     u32 ypad;              // side-buffer stride in words (>= 2*band+2)
     u64 ckpt_off;          // word offsets inside a slot of the direction-free fill's row / boundary stores
     u64 bnd_off;           // (0 = this launch keeps directions everywhere)
-    u64 val_off;           // packed kernels: word offset inside a slot of the value images (two per task of the wavefront)
     u32 flags;             // LP_*
     // Issue priority by remaining work (kernel_common.inc, set_prio_by_remaining): the units (tasks / pairs / quads / octets)
     // from index prio_from on raise their wavefront's s_setprio level while they have many blocks left, measured against
@@ -106,7 +105,7 @@ enum KernelId : int {
 // the device).  Returns ST_OK (0) when the call has to run (then *X_out = rows of the band matrix), otherwise the final
 // status the reference's behaviour maps to (1 EMPTY, 2 OUT_OF_RANGE, 3 INVALID = GAMDP_ST_*); *cells_out = x_size * y_size
 // whenever the reference got as far as sizing its matrix.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GAMDP_HD __host__ __device__
 #else
 #define GAMDP_HD
@@ -228,6 +227,5 @@ int kernel_waves_per_cu(int kid);
 int kernel_bnd_words(int kid);  // boundary words per block of the direction-free kernels
 int kernel_ckpt_words(int kid);      // words per group (4 blocks) of the live-row store of the direction-free kernels
 int kernel_tasks_per_wave(int kid);
-int kernel_vimg_words(int kid);      // words of one value image of the packed kernels (0 for the others)  // 4 for the K_Q* variants (their task list is padded to a multiple of 4), else 1
 
 }  // namespace gamdp

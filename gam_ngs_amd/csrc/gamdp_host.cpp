@@ -562,7 +562,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     u64 n_host_tasks = 0;
     std::vector<u64>& cells_key = w_key;
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
-    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off, val_off; };
+    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; };
     std::vector<Launch> launches;
     std::vector<std::vector<u32>> launch_items;   // the tasks of every launch, in launch order (staged once the plan is complete)
     // (Measured and dropped: handing the leftover of a multi-task group -- less than one round -- to a finer-grained kernel
@@ -603,9 +603,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);
             }
             const u64 dir_total = pair ? 2 * dirw : dirw;
-            // the packed kernels walk their direction-free blocks on cell values: two value images per task (kernel_vstrip.inc)
-            const u64 val_words = ckpt_words ? 2ull * tpw * (u64)kernel_vimg_words(kid) : 0;
-            const u64 slotw = dir_total + 4ull * ypad * tpw + ckpt_words + bnd_words + val_words;
+            const u64 slotw = dir_total + 4ull * ypad * tpw + ckpt_words + bnd_words;
             const u64 fit = arena_call / (slotw * sizeof(u32));
             if (fit == 0) { set_error("scratch arena too small for one task"); return GAMDP_ENOMEM; }
             const u64 want = std::min<u64>((cur.size() + tpw - 1) / tpw, max_resident);
@@ -629,7 +627,6 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             L.dyn_lds = 0;
             L.ckpt_off = ckpt_words ? dir_total + 4ull * ypad * tpw : 0;
             L.bnd_off = L.ckpt_off + ckpt_words;
-            L.val_off = L.bnd_off + bnd_words;
             n_host_tasks += padded;
             launch_items.push_back(std::move(cur));
             launches.push_back(L);
@@ -707,7 +704,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.tasks = d_tasks + L.first; p.n_tasks = L.count; p.cursor = d_cursor + li;
             p.results = d_results; p.ops_buf = d_ops;
             p.scratch = d_scratch; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
-            p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off; p.val_off = L.val_off;
+            p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
             static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::atol(e) : 2ull; }();
             p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
             {   // longest-remaining-first issue priority for the units in flight when the queue runs dry (gamdp_dev.h)

@@ -51,7 +51,6 @@ __shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise
 #include "kernel_fill.inc"
 #include "kernel_pair.inc"
 #include "kernel_strip.inc"
-#include "kernel_vstrip.inc"
 #include "kernel_finish.inc"
 
 // ---- the whole task -------------------------------------------------------------------------------
@@ -71,7 +70,6 @@ __device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams&
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.vimg = (gptr)slot;
     t.df_lo = t.df_hi = 0;
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
@@ -166,7 +164,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align(const Launch
 }
 
 // ---- two tasks per wavefront, fast blocks in packed f16 (kernel_pair.inc) -------------------------------------------
-__device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, u32* dir, u32* side, u32* slot, const u32 vimg_words = 0, const u32 task_in_wave = 0)
+__device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, u32* dir, u32* side, u32* slot)
 {
     Tk t;
     t.a2 = as_global(dt.a2); t.an = as_global(dt.an); t.b2 = as_global(dt.b2); t.bn = as_global(dt.bn);
@@ -181,7 +179,6 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.vimg = (gptr)(slot + p.val_off + (u64)task_in_wave * 2u * vimg_words);
     t.df_lo = t.df_hi = 0;
     t.prio_R = t.prio_nblk = 0;
     t.cancel = nullptr;
@@ -286,7 +283,6 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
 }
 
 #include "kernel_walk.inc"
-#include "kernel_vwalk.inc"
 
 // end cell, walk and result of the NT tasks of a wavefront: the end cells one task at a time (the whole wavefront scans),
 // the interior of all walks side by side (walk_many), then per task the steps the reference treats specially + the result
@@ -316,7 +312,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
 #endif
     // (with four int32 tasks the side-by-side walk spends as many vector instructions per task as the one-task walk, which
     // keeps its bookkeeping on the scalar unit: measured 6 % slower on 98 304 x 50 kb; eight packed tasks: 4 % faster)
-    if constexpr ((NT == 8 || LPT == 64) && !(GAMDP_VALUE_STRIPS && PK && !HASN))   // (the value-strip experiment has no side-by-side walk)
+    if constexpr (NT == 8 || LPT == 64)
         if (side_by_side && skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane);
 #ifdef GAMDP_EXP_PHASES
     const long long tp2 = wall_clock64();
@@ -327,10 +323,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
     for (int s = 0; s < NT; ++s) {
         const Tk ts = task_tk(s);
         const int lb = (LPT == 64) ? 0 : QL * (s & 3), hs = (LPT == 64) ? s : s >> 2;
-        // (packed kernels: finish_walk stops wherever the walk enters the direction-free blocks; walk_values takes it through them)
-        while (!finish_walk<C, CE, HASN, LPT, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s])) {
-            if constexpr (GAMDP_VALUE_STRIPS && PK && !HASN) walk_values<C, CE, LPT>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);
-        }
+        finish_walk<C, CE, HASN, LPT, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);
     }
 #ifdef GAMDP_EXP_PHASES
     {   // timing experiment: the first task's record carries the phase times of the wavefront (10 ns ticks)
@@ -352,8 +345,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
 #endif
     // slot: [dir A][dir B][side buffers A][side buffers B][packed rows][packed boundaries]
     u32* const sideA = slot + 2 * p.dir_words;
-    Tk ta = make_tk(da, p, slot, sideA, slot, VImg<C, 64>::WORDS, 0);
-    Tk tb = make_tk(db, p, slot + p.dir_words, sideA + 4u * p.ypad, slot, VImg<C, 64>::WORDS, 1);
+    Tk ta = make_tk(da, p, slot, sideA, slot);
+    Tk tb = make_tk(db, p, slot + p.dir_words, sideA + 4u * p.ypad, slot);
     const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);
     // the packed range: fast blocks of BOTH tasks, whole groups of 4 blocks, at least one tagged fast block in front of it
     // for either task (what a lane receives at a group start must be its neighbour's plain last column)
@@ -431,7 +424,6 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.vimg = (gptr)slot;
     t.df_lo = t.df_hi = 0;
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
@@ -530,8 +522,8 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     const DevTask& db = p.tasks[8 * qi + 4u + (u32)sub];
     // slot: [dir quad A][dir quad B][side buffers of the 8 tasks][packed rows][packed boundaries]
     u32* const side = slot + 2 * p.dir_words;
-    Tk ta = make_tk(da, p, slot, side + (u64)sub * 4u * p.ypad, slot, VImg<C, QL>::WORDS, (u32)sub);
-    Tk tb = make_tk(db, p, slot + p.dir_words, side + (u64)(4 + sub) * 4u * p.ypad, slot, VImg<C, QL>::WORDS, 4u + (u32)sub);
+    Tk ta = make_tk(da, p, slot, side + (u64)sub * 4u * p.ypad, slot);
+    Tk tb = make_tk(db, p, slot + p.dir_words, side + (u64)(4 + sub) * 4u * p.ypad, slot);
 #ifdef GAMDP_EXP_PHASES
     const long long tf0 = wall_clock64();
     g_exp_mat_ticks = 0;
@@ -725,7 +717,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = (u64)uni64((int64_t)mbp->slot_words); p.dir_words = (u64)uni64((int64_t)mbp->dir_words); p.ypad = cp.ypad;
-    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.flags = 0; p.prio_R = 0; p.prio_from = 0;
     if constexpr (HASN) {
         if (uni((int)cp.mbs[mi].has_n) != 0) run_chain<true>(cp, p, mi, slot, lane);
         else run_chain<false>(cp, p, mi, slot, lane);
@@ -888,7 +880,7 @@ __device__ __forceinline__ void chain_walker(const LaunchParams& p, const int la
         WalkCarry wc;
         end_cell<5, true>(&s_mail.tk[par], lane, &wc);
         wc.early_seq = w + 1;
-        (void)finish_walk<5, 0, HASN, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
+        finish_walk<5, 0, HASN, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
     }
 }
 
@@ -905,7 +897,7 @@ __global__ __launch_bounds__(64 * (1 + CH_NW), GAMDP_WAVES_PER_SIMD) void k_chai
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = (u64)uni64((int64_t)mbp->slot_words); p.dir_words = (u64)uni64((int64_t)mbp->dir_words); p.ypad = cp.ypad;
-    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.val_off = 0; p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.flags = 0; p.prio_R = 0; p.prio_from = 0;
     if (threadIdx.x == 0) {
         s_mail.filled = 0; s_mail.quit = 0; s_mail.total = 0; s_mail.claim = 0; s_mail.n_done = 0;
         for (int k = 0; k < CH_NS; ++k) { s_mail.early_of[k] = 0; s_mail.done_of[k] = 0; }
@@ -985,14 +977,6 @@ bool kernel_dirfree(int kid)
     case K_C5_CE0: case K_C5_CE0_N: return GAMDP_DF5 != 0;
     default: return false;
     }
-}
-
-int kernel_vimg_words(int kid)
-{
-    if (!GAMDP_VALUE_STRIPS) return 0;
-    if (kid == K_P17_CE4) return (int)VImg<17, 64>::WORDS;
-    if (kid == K_O19_CE15) return (int)VImg<19, QL>::WORDS;
-    return 0;
 }
 
 int kernel_bnd_words(int kid)
