@@ -44,6 +44,9 @@ class Context:
     def set_arena_bytes(self, nbytes: int):
         _check(self, self.lib.gamdp_ctx_set_arena_bytes(self.handle, nbytes), "gamdp_ctx_set_arena_bytes")
 
+    def last_error(self):
+        return (self.lib.gamdp_last_error(self.handle) or b"").decode()
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         self.lib.gamdp_ctx_kernel_time(self.handle, C.byref(ms), C.byref(n), int(reset))

@@ -184,13 +184,17 @@ struct DevMB {
     u32 try_rev;                   // orientation of the first attempt
     u32 has_n;                     // one of its two contigs holds an N: the chain runs the N-aware cells (12% slower)
     // its scratch: slots sized for ITS longest call (x_size <= its longest slave frame), not the launch's
-    u32 pad0;
+    u32 max_x;                     // the rows a slot has room for: a call that needs more ends the chain with state 3 (the host's round loop takes the merge block)
     u64 slot_off[2];               // word offset in ChainParams::scratch of the first slot of its workgroup / of its twin's (within the piece of the launch it is in)
     u64 slot_words, dir_words;     // words per slot; direction words at the start of a slot (side buffers follow)
     u64 ckpt_off, bnd_off;         // as in LaunchParams (0 = directions everywhere)
 };
 struct ChainOut { u32 n_dp; u32 state; u32 t_begin, t_end; u32 hw, hw_twin; u32 t_end_att[2]; u32 t_begin2; u32 pad; };   // t_*: the device's 100 MHz clock (low word) when the chain's workgroup started / ended (timing diagnostics)
-//   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid; bit 8: rev
+//   // state: 0 main chain good (rev = orientation), 1 both attempts failed, 2 a call threw / was invalid, 3 a call did not fit the
+//   // chain's scratch slots (nothing of the chain is used: the host takes the merge block through its round loop); bit 8: rev
+// What a call of a chain was run on, next to its result record (same index): the window the device derived (PctgBuilder.cc:1652-1677),
+// the orientation, the rows and the status of the pre-checks.  The host's replay derives the same call by itself and compares.
+struct ChainWin { u64 begin_a, end_a, begin_b, end_b; u32 X; u32 info; };   // info: bit 0 = the slave reverse-complemented, bits 8.. = status of the pre-checks (0 = the DP ran)
 // A long chain gets a twin: a second workgroup that runs the OTHER orientation (findBestAlignment's second attempt, :1463-1509)
 // at the same time instead of after the first has failed -- the merge blocks that need it (a first guess that was wrong, a merge
 // block that fails) are the ones a call waits for.  The two never wait for each other: each leaves its verdict here, and the one
@@ -205,12 +209,15 @@ struct ChainParams {
     u32 first_mb;                  // the launch takes merge blocks first_mb .. first_mb + grid - 1
     u32* cursor;
     DevResult* audit; ChainOut* out;
+    ChainWin* win;                 // [2 * blocks], parallel to audit
     u32* scratch; u32 ypad; u32 band;   // (slot geometry: per merge block, DevMB)
     u32 max_rows;                  // the largest DevMB::rows of the call: chains with many rows left go first (set_prio_by_remaining)
     // the host's view while the launch runs (pinned, coherent host memory, device pointers): a chain that ends copies its
     // records and its ChainOut there and then raises its flag (done[mi] = epoch, system-scope release), so the host takes a
     // merge block on (replay, tail alignments) while longer chains are still going
     DevResult* host_audit; ChainOut* host_out; u32* host_done; u32 epoch;
+    ChainWin* host_win;
+    u32 skew_call;                 // diagnostics build only (GAMDP_DIAG_CHAIN_SKEW=k): the device starts call k of every first attempt one base late on the slave; ~0u = off
     u32 two_waves;                 // k_chain2: a workgroup of one filling and several walking wavefronts with chain_slots_per_workgroup() scratch slots of slot_words each
 };
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int

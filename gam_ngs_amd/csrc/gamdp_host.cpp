@@ -281,12 +281,15 @@ Ctx::~Ctx()
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-u64 Ctx::arena_budget()
+u64 Ctx::arena_budget(const bool refresh)
 {
-    if (arena_limit == 0) {
+    if (arena_limit == 0 || (refresh && arena_auto)) {
         size_t fr = 0, tot = 0;
         if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-        arena_limit = (u64)((double)(fr + (cap_scratch + cap_chain_scratch) * sizeof(u32)) * 0.75);
+        u64 held = cap_scratch + cap_chain_scratch;
+        for (const Ctx* h : helpers) held += h->cap_scratch + h->cap_chain_scratch;
+        arena_limit = (u64)((double)(fr + held * sizeof(u32)) * 0.75);
+        arena_auto = true;
     }
     return arena_limit;
 }
@@ -787,6 +790,7 @@ int gamdp_ctx_set_arena_bytes(gamdp_ctx* ctx, uint64_t bytes)
     if (!ctx) return GAMDP_EINVAL;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     c->arena_limit = bytes;                           // 0 = back to the automatic budget
+    c->arena_auto = bytes == 0;
     for (Ctx* h : c->helpers) h->arena_limit = bytes; // (every call hands the owner's budget to its helpers again anyway)
     return 0;
 }
@@ -843,6 +847,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     const SeqSet* sa = reinterpret_cast<const SeqSet*>(set_a);
     const SeqSet* sb = reinterpret_cast<const SeqSet*>(set_b);
     return guarded(c, [&]() -> int {
+    if (c->arena_budget(true) == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
     auto run = [&](Ctx* cc, size_t first, size_t cnt) -> int {
         if (cc->w_tasks.size() < cnt) cc->w_tasks.resize(cnt);
         std::vector<ITask>& it = cc->w_tasks;

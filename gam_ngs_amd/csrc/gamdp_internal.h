@@ -87,8 +87,12 @@ struct Ctx {
     // that run at the same time on the device (the two of a chunked batch, the K cohorts of a merge-block call; set by
     // the entry point for the duration of the call, which also hands the owner's budget to its helpers).
     u64 arena_limit = 0;
+    bool arena_auto = true;   // arena_limit was determined from the free memory, not set by the caller
     u32 arena_share = 1, arena_div = 1;
-    u64 arena_budget();   // determines the automatic budget on first use
+    // The automatic budget: 75 % of (free HBM + what this context and its helper contexts hold as scratch).  Determined on first
+    // use and again at every entry point of the C ABI (`refresh`): sequence sets created or destroyed between calls, reverse
+    // complements uploaded on demand and other users of the device move what is free.
+    u64 arena_budget(bool refresh = false);
     u64 arena_call() const { return arena_limit / ((u64)(arena_share ? arena_share : 1) * (u64)(arena_div ? arena_div : 1)); }
     void trim_scratch();  // gives back a scratch allocation larger than this call's share (before helper contexts allocate theirs)
 

@@ -603,7 +603,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
     const u64 align_thr = (u64)uni64((int64_t)mb->align_thr);
     const u32 first_blk = (u32)uni((int)mb->first_blk), n = (u32)uni((int)mb->n_blocks), audit_first = (u32)uni((int)mb->audit_first);
-    const u32 band = cp.band;
+    const u32 band = cp.band, max_x = (u32)uni((int)mb->max_x);
     bool try_rev = uni((int)mb->try_rev) != 0;
     auto frame_len = [](const int32_t b, const int32_t e) -> int32_t { return e < b ? 0 : e - b + 1; };   // Frame.cc:124-127
     u32 n_dp = 0, state = 1;
@@ -611,7 +611,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         int64_t cur_ms = (int64_t)m_start;
         int64_t cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);   // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
         u64 last_a = 0, last_b = 0, sumlen = 0;
-        bool all_good = true, thrown = false;
+        bool all_good = true, thrown = false, overflow = false;
         int rows_left = uni((int)mb->rows);
         for (u32 k = 0; k < n; ++k) {
             const DevBlk* bk = unip(cp.blks + first_blk + k);
@@ -624,6 +624,9 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
                 cur_ms = (int64_t)(last_a + (u64)(int64_t)mgap); if (cur_ms < 0) cur_ms = 0;
                 cur_ss = (int64_t)(last_b + (u64)(int64_t)sgap); if (cur_ss < 0) cur_ss = 0;
             }
+#ifdef GAMDP_DIAG
+            if (attempt == 0 && k == cp.skew_call) ++cur_ss;   // fault injection (GAMDP_DIAG_CHAIN_SKEW): the host's replay must notice
+#endif
             const u64 begin_a = (u64)cur_ms, end_a = (u64)(cur_ms + ml - 1), begin_b = (u64)cur_ss, end_b = (u64)(cur_ss + sl - 1);
             // the call ends when its longest chain does: wavefronts that share a SIMD yield to the one with the most rows left
             set_prio_by_remaining(rows_left, (int)cp.max_rows);
@@ -631,6 +634,8 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
             u64 X = 0, cells = 0;
             const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
             const u32 idx = audit_first + n_dp;
+            if (st == 0 && X > (u64)max_x) { overflow = true; break; }   // (the host sized the slot for the chain's longest slave frame: never, unless its arithmetic and this one differ)
+            if (lane == 0) { ChainWin w; w.begin_a = begin_a; w.end_a = end_a; w.begin_b = begin_b; w.end_b = end_b; w.X = (u32)X; w.info = (try_rev ? 1u : 0u) | ((u32)st << 8); cp.win[idx] = w; }
 #ifdef GAMDP_DIAG
             if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x1000u | ((u32)st << 16) | (k << 20); cp.out[mi] = o; }   // progress marker (overwritten at the end)
 #endif
@@ -681,6 +686,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
 #ifdef GAMDP_DIAG
         if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x4000u | (all_good ? 1u : 0u) | (thrown ? 2u : 0u) | ((sumlen >= align_thr) ? 4u : 0u); cp.out[mi] = o; }
 #endif
+        if (overflow) { state = 3; break; }
         if (thrown) { state = 2; break; }
         if (all_good && sumlen >= align_thr) { state = try_rev ? 0x100u : 0u; break; }   // is_good(vector), :1711-1724
         if (++attempt == 2) { state = 1; break; }                                          // :1512
@@ -695,6 +701,10 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
         const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
         for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
+        const u32* wsrc = reinterpret_cast<const u32*>(cp.win + audit_first);
+        u32* wdst = reinterpret_cast<u32*>(cp.host_win + audit_first);
+        const u32 nww = n_dp * (u32)(sizeof(ChainWin) / sizeof(u32));
+        for (u32 w = (u32)lane; w < nww; w += 64) wdst[w] = wsrc[w];
         if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
 
 // ---- the same chain by two wavefronts: one fills, one walks ------------------------------------------------------------------
 // A lone wavefront issues one instruction every ~5 cycles whatever it does, and a fifth of a chain's instructions are the end-cell
-// search and the walk (measured, tools/r03_probe8.sh: 50 kb band-150 calls one per CU, 3.81 ms fill + 1.00 ms walk).  The next
+// search and the walk (measured, tools/lab_r03/r03_probe8.sh: 50 kb band-150 calls one per CU, 3.81 ms fill + 1.00 ms walk).  The next
 // call of a chain needs one thing from the walk of this one: the last match (PctgBuilder.cc:1660-1667), which is the FIRST match
 // the walk meets.  So the workgroup has two wavefronts and two scratch slots: wavefront 0 fills call k + 1 into one slot while
 // wavefront 1 walks call k in the other (ChainMail, kernel_finish.inc).  Same calls, same records, same order in the audit list.
@@ -741,7 +751,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
     const u64 align_thr = (u64)uni64((int64_t)mb->align_thr);
     const u32 first_blk = (u32)uni((int)mb->first_blk), n = (u32)uni((int)mb->n_blocks), audit_first = (u32)uni((int)mb->audit_first);
-    const u32 band = cp.band;
+    const u32 band = cp.band, max_x = (u32)uni((int)mb->max_x);
     bool try_rev = (uni((int)mb->try_rev) != 0) != (role == 2);
     auto frame_len = [](const int32_t b, const int32_t e) -> int32_t { return e < b ? 0 : e - b + 1; };   // Frame.cc:124-127
     ChainSync* const sy = role != 0 ? cp.sync + mi : nullptr;
@@ -752,7 +762,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         int64_t cur_ms = (int64_t)m_start;
         int64_t cur_ss = (int64_t)(try_rev ? slen - s_end - 1 : s_start);   // reverse_complement maps (start,end) -> (|s|-end-1, |s|-start-1), :1446-1448
         u64 last_a = 0, last_b = 0;
-        bool settled_bad = false, thrown = false;
+        bool settled_bad = false, thrown = false, overflow = false;
         int rows_left = uni((int)mb->rows);
         // (the walkers are idle here: every call handed over so far is done)
         if (lane == 0) { s_mail.bad = 0; s_mail.sum = 0; }
@@ -769,12 +779,17 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
                 cur_ms = (int64_t)(last_a + (u64)(int64_t)mgap); if (cur_ms < 0) cur_ms = 0;
                 cur_ss = (int64_t)(last_b + (u64)(int64_t)sgap); if (cur_ss < 0) cur_ss = 0;
             }
+#ifdef GAMDP_DIAG
+            if (attempt == 0 && k == cp.skew_call) ++cur_ss;   // fault injection (GAMDP_DIAG_CHAIN_SKEW): the host's replay must notice
+#endif
             const u64 begin_a = (u64)cur_ms, end_a = (u64)(cur_ms + ml - 1), begin_b = (u64)cur_ss, end_b = (u64)(cur_ss + sl - 1);
             set_prio_by_remaining(rows_left, (int)cp.max_rows);
             rows_left -= sl;
             u64 X = 0, cells = 0;
             const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
             const u32 idx = audit_first + n_dp;
+            if (st == 0 && X > (u64)max_x) { overflow = true; break; }   // (the host sized the slots for the chain's longest slave frame: never, unless its arithmetic and this one differ)
+            if (lane == 0) { ChainWin w; w.begin_a = begin_a; w.end_a = end_a; w.begin_b = begin_b; w.end_b = end_b; w.X = (u32)X; w.info = (try_rev ? 1u : 0u) | ((u32)st << 8); cp.win[idx] = w; }
             u32 status;
             if (st != 0) {   // settled without a DP, exactly as the host settles it (Ctx::align)
                 DevResult r;
@@ -816,6 +831,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         const bool all_good = !settled_bad && uni(s_mail.bad) == 0;
         const u64 sumlen = (u64)uni64((int64_t)s_mail.sum);
         if (cancelled) { state = 1; break; }   // (whatever: nobody looks at a cancelled twin's verdict)
+        if (overflow) { state = 3; break; }
         if (thrown) { state = 2; break; }
         if (all_good && sumlen >= align_thr) { state = try_rev ? 0x100u : 0u; break; }
         if (++attempt == 2 || role == 1) { state = 1; break; }                             // :1512 (role 1: the second attempt is the twin's)
@@ -859,6 +875,10 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         u32* dst = reinterpret_cast<u32*>(cp.host_audit + audit_first);
         const u32 nw = n_dp * (u32)(sizeof(DevResult) / sizeof(u32));
         for (u32 w = (u32)lane; w < nw; w += 64) dst[w] = src[w];
+        const u32* wsrc = reinterpret_cast<const u32*>(cp.win + audit_first);
+        u32* wdst = reinterpret_cast<u32*>(cp.host_win + audit_first);
+        const u32 nww = n_dp * (u32)(sizeof(ChainWin) / sizeof(u32));
+        for (u32 w = (u32)lane; w < nww; w += 64) wdst[w] = wsrc[w];
         if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);

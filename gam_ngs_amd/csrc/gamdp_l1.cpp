@@ -129,6 +129,7 @@ struct Machine {
     // audit
     gamdp_result* audit = nullptr;
     u32 audit_cap = 0;
+    bool on_device = false;   // its main chain is part of the chain launch of this call (launch_main_chains)
 
     const gamdp_block& blk(u32 i) const { return forward ? in->blocks[i] : in->blocks[in->n_blocks - 1 - i]; }
 
@@ -362,6 +363,7 @@ struct ChainRun {
     const DevMB* hmb = nullptr;
     const ChainOut* hout = nullptr;
     const DevResult* haud = nullptr;
+    const ChainWin* hwin = nullptr;
     const volatile u32* done = nullptr;
     u32 epoch = 0;
     hipStream_t stream = nullptr;
@@ -441,9 +443,16 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     run.launched = false;
     static const bool rounds_only = std::getenv("GAMDP_L1_ROUNDS") != nullptr;
     if (rounds_only || band != 150) return 0;
+    // A merge block with an empty slave frame (s_end < s_begin) stays with the round loop: the call of such a block that
+    // starts at slave base 0 has end_b = begin_b - 1 wrapped around (the reference computes it in unsigned long,
+    // PctgBuilder.cc:1669-1677), so its rows are bounded by the contig, not by the frame the scratch slots below are sized for.
     std::vector<u32> act;
-    for (u32 i = 0; i < (u32)M.size(); i++)
-        if (M[i].phase == Machine::MAIN) act.push_back(i);
+    for (u32 i = 0; i < (u32)M.size(); i++) {
+        if (M[i].phase != Machine::MAIN) continue;
+        bool empty_frame = false;
+        for (u32 k = 0; k < M[i].in->n_blocks; k++) empty_frame = empty_frame || M[i].in->blocks[k].s_end < M[i].in->blocks[k].s_begin;
+        if (!empty_frame) act.push_back(i);
+    }
     if (act.empty()) return 0;
     // longest chains first
     std::vector<u64> w(act.size(), 0);
@@ -479,8 +488,9 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     if (!no_twins)
         while (n_tw < n_mb && n_tw < tw_cap && w[order[n_tw]] * 8 >= w[order[0]] && w[order[n_tw]] >= 1024) n_tw++;
     const u64 off_mb = 0, off_blk = up(off_mb + n_mb * sizeof(DevMB)), off_sync = up(off_blk + n_blk * sizeof(DevBlk)), off_out = up(off_sync + (n_tw + 1) * sizeof(ChainSync)),
-              off_aud = up(off_out + n_mb * sizeof(ChainOut)), total = up(off_aud + n_audit * sizeof(DevResult));
-    const u64 mo_out = 0, mo_done = up(mo_out + n_mb * sizeof(ChainOut)), mo_aud = up(mo_done + n_mb * sizeof(u32)), mtotal = up(mo_aud + n_audit * sizeof(DevResult));
+              off_aud = up(off_out + n_mb * sizeof(ChainOut)), off_win = up(off_aud + n_audit * sizeof(DevResult)), total = up(off_win + n_audit * sizeof(ChainWin));
+    const u64 mo_out = 0, mo_done = up(mo_out + n_mb * sizeof(ChainOut)), mo_aud = up(mo_done + n_mb * sizeof(u32)), mo_win = up(mo_aud + n_audit * sizeof(DevResult)),
+              mtotal = up(mo_win + n_audit * sizeof(ChainWin));
     if (total > c->cap_chain) {
         if (c->d_chain) (void)hipFree(c->d_chain);
         c->d_chain = nullptr; c->cap_chain = 0;
@@ -562,7 +572,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
         const u64 nblk = ((u64)longest[order[q]] - 1 + LE) / 16 + 1;
         const u64 dirw = ((nblk * (u64)kernel_dir_block_words(K_C5_CE0_N) + 63) / 64) * 64;
         const u64 ckptw = df ? (nblk / 4 + 2) * (u64)kernel_ckpt_words(K_C5_CE0_N) : 0, bndw = df ? (nblk + 4) * (u64)kernel_bnd_words(K_C5_CE0_N) : 0;
-        x.pad0 = 0;
+        x.max_x = longest[order[q]];
         x.dir_words = dirw; x.slot_words = dirw + 4ull * ypad + ckptw + bndw;
         x.ckpt_off = df ? dirw + 4ull * ypad : 0; x.bnd_off = x.ckpt_off + ckptw;
         slotw_max = std::max(slotw_max, x.slot_words);
@@ -601,17 +611,19 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     cp.mbs = (const DevMB*)(d + off_mb); cp.blks = (const DevBlk*)(d + off_blk); cp.n_mbs = (u32)n_mb;
     cp.n_twins = (u32)n_tw; cp.sync = (ChainSync*)(d + off_sync);
     std::memset(h + off_sync, 0, (n_tw + 1) * sizeof(ChainSync));
-    cp.cursor = nullptr; cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out);
+    cp.cursor = nullptr; cp.audit = (DevResult*)(d + off_aud); cp.out = (ChainOut*)(d + off_out); cp.win = (ChainWin*)(d + off_win);
     cp.scratch = c->d_chain_scratch; cp.ypad = ypad; cp.band = band;
     cp.max_rows = (u32)std::min<u64>(std::max<u64>(1, w[order[0]]), 0x7fffffffu);
-    cp.host_out = (ChainOut*)(dm + mo_out); cp.host_done = (u32*)(dm + mo_done); cp.host_audit = (DevResult*)(dm + mo_aud);
+    cp.host_out = (ChainOut*)(dm + mo_out); cp.host_done = (u32*)(dm + mo_done); cp.host_audit = (DevResult*)(dm + mo_aud); cp.host_win = (ChainWin*)(dm + mo_win);
     cp.epoch = c->chain_epoch;
+    cp.skew_call = ~0u;
+    if (diag().build) { static const char* const e = std::getenv("GAMDP_DIAG_CHAIN_SKEW"); if (e) cp.skew_call = (u32)std::atoi(e); }
     cp.two_waves = one_wave ? 0u : 1u;
     if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %zu piece(s), %.1f MB of scratch (slots of up to %llu words), %llu twins, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, pieces.size(), need_scratch * 4e-6, (unsigned long long)slotw_max, (unsigned long long)n_tw, (int)has_n);
     run.n_mb = n_mb; run.band = band; run.hmb = hmb;
-    run.hout = (const ChainOut*)(hm + mo_out); run.done = (const volatile u32*)(hm + mo_done); run.haud = (const DevResult*)(hm + mo_aud);
+    run.hout = (const ChainOut*)(hm + mo_out); run.done = (const volatile u32*)(hm + mo_done); run.haud = (const DevResult*)(hm + mo_aud); run.hwin = (const ChainWin*)(hm + mo_win);
     run.epoch = cp.epoch; run.stream = c->chain_stream; run.dout = cp.out;
     run.t_launch = std::chrono::steady_clock::now();
     bool ok = hipMemcpyAsync(d, h, off_out, hipMemcpyHostToDevice, c->chain_stream) == hipSuccess;
@@ -628,10 +640,15 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
         return GAMDP_EHIP;
     }
     run.launched = true;
+    for (u32 i : act) M[i].on_device = true;
     return 0;
 }
 
-// The host's machine of merge block `mi` over the records its chain left (after run.ended()).
+// The host's machine of merge block `mi` over the records its chain left (after run.ended()).  Every call of the chain is
+// derived twice: the device left, next to each result record, the window it ran (ChainWin), the host's machine derives its own
+// next call from the records so far (Machine::pending, PctgBuilder.cc:1652-1677) and runs its own pre-checks; the two must
+// agree in every number -- window, orientation, rows, status -- or the call fails with GAMDP_EHIP naming the merge block and the
+// call: a chain kernel that derived a different window can not hand back a plausible wrong answer.
 int replay_chain(Ctx* cc, const ChainRun& run, Machine& m, const u32 mi)
 {
     static std::unordered_map<u32, std::vector<uint8_t>> no_cache;   // (never touched: the MAIN phase does not look at the slave's codes)
@@ -639,15 +656,34 @@ int replay_chain(Ctx* cc, const ChainRun& run, Machine& m, const u32 mi)
     const u32 q = run.q_of[mi];
     const DevMB& x = run.hmb[q];
     const u32 n_dp = run.hout[q].n_dp;
+    if ((run.hout[q].state & 0xffu) == 3u) {   // a call did not fit the chain's scratch slots: nothing of the chain is used, the round loop takes the merge block
+        m.on_device = false;
+        return 0;
+    }
     u32 used = 0;
+    auto differs = [&](const char* what, const u64 dev, const u64 host) {
+        cc->set_error("internal: merge block " + std::to_string(mi) + ", call " + std::to_string(used) + " of its chain: the device's " + what + " is " +
+                      std::to_string(dev) + ", the host's " + std::to_string(host));
+        return GAMDP_EHIP;
+    };
     while (m.phase == Machine::MAIN) {
         if (used >= n_dp) { cc->set_error("internal: the device's chain of merge block " + std::to_string(mi) + " is shorter than the host's"); return GAMDP_EHIP; }
         ITask t;
         m.pending(t, no_cache, no_mu);
         u64 X = 0, cells = 0;
-        (void)preflight(m.mlen, m.slen, run.band, t.begin_a, t.end_a, t.begin_b, t.end_b, false, false, &X, &cells);
+        const int st = preflight(m.mlen, m.slen, run.band, t.begin_a, t.end_a, t.begin_b, t.end_b, false, false, &X, &cells);
+        const ChainWin& w = run.hwin[x.audit_first + used];
+        const DevResult& rec = run.haud[x.audit_first + used];
+        if (w.begin_a != t.begin_a) return differs("begin_a", w.begin_a, t.begin_a);
+        if (w.end_a != t.end_a) return differs("end_a", w.end_a, t.end_a);
+        if (w.begin_b != t.begin_b) return differs("begin_b", w.begin_b, t.begin_b);
+        if (w.end_b != t.end_b) return differs("end_b", w.end_b, t.end_b);
+        if ((w.info & 1u) != (t.b_rc ? 1u : 0u)) return differs("orientation", w.info & 1u, t.b_rc ? 1u : 0u);
+        if ((w.info >> 8) != (u32)st) return differs("pre-check status", w.info >> 8, (u64)st);
+        if (w.X != (u32)X) return differs("row count", w.X, X);
+        if (st != GAMDP_ST_OK && (rec.flags >> 8) != (u32)st) return differs("record status", rec.flags >> 8, (u64)st);
         gamdp_result r;
-        fill_result(run.haud[x.audit_first + used], cells, r);
+        fill_result(rec, cells, r);
         m.feed(r);
         used++;
     }
@@ -674,7 +710,7 @@ void run_cohort(Ctx* c, std::vector<Machine>& M, const std::vector<u32>& ids, st
     const bool chained = run && run->launched;
     if (chained)
         for (u32 i : ids)
-            if (M[i].phase == Machine::MAIN && run->q_of[i] != ~0u) waiting.push_back(i);
+            if (M[i].phase == Machine::MAIN && M[i].on_device) waiting.push_back(i);
     bool drained = false;   // the chain launch is known to be complete
     for (;;) {
         const auto t0 = now();
@@ -690,7 +726,7 @@ void run_cohort(Ctx* c, std::vector<Machine>& M, const std::vector<u32>& ids, st
         }
         owner.clear();
         for (u32 i : ids)
-            if (M[i].phase != Machine::DONE && !(chained && M[i].phase == Machine::MAIN)) owner.push_back(i);
+            if (M[i].phase != Machine::DONE && !(M[i].phase == Machine::MAIN && M[i].on_device)) owner.push_back(i);
         if (owner.empty()) {
             if (waiting.empty()) break;
             // nothing to do until a chain ends; a launch that is over without every flag up has failed
@@ -799,7 +835,7 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
     }
     // the K cohort contexts share the device for this call: 1/K of the owner's budget each, whatever was set or
     // determined before (helpers that already exist included)
-    if (c->arena_budget() == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
+    if (c->arena_budget(true) == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
     struct DivGuard {
         Ctx* c; int K;
         ~DivGuard() { c->arena_div = 1; for (int k = 1; k < K; k++) c->helpers[(size_t)k - 1]->arena_div = 1; }
@@ -832,6 +868,13 @@ extern "C" int gamdp_align_merge_blocks(gamdp_ctx* ctx, const gamdp_seqset* mast
         if (rc_chain) return rc_chain;
     }
     const bool chained = run.launched;
+    if (!chained) {
+        // no chain launch after all (another band, GAMDP_L1_ROUNDS=1, no main chain to run, a frame too long for the slots):
+        // the round loops get the whole budget, not the half that was kept for the launch's scratch slots
+        c->arena_div = (u32)K;
+        for (int k = 1; k < K; k++) c->helpers[(size_t)k - 1]->arena_div = (u32)K;
+        if (c->d_chain_scratch) { (void)hipFree(c->d_chain_scratch); c->d_chain_scratch = nullptr; c->cap_chain_scratch = 0; }
+    }
     float chain_ms = 0, chain_at = 0;
     struct FreeGuard {   // (see Ctx::defer_frees)
         Ctx* c; int K;

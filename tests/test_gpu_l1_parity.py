@@ -65,6 +65,38 @@ def test_merge_blocks_with_a_small_scratch_arena(arena_kb):
     assert stats["ok"] >= 15 and stats["bad"] >= 5, stats
 
 
+def test_merge_blocks_with_an_empty_slave_frame_at_the_start_of_the_slave():
+    """A frame with s_end < s_begin has length 0 (Frame.cc:124-127).  When the call of such a block starts at slave base 0 the
+    reference's end_b = begin_b + 0 - 1 wraps around (unsigned long, PctgBuilder.cc:1669-1677), find_alignment clips it to
+    |b| - 1, and the call aligns the WHOLE slave -- far more rows than any frame of the merge block has (the chain
+    kernel's scratch slots are sized by the longest frame).  Such merge blocks stay with the round loop; here they sit in one
+    batch with ordinary ones, as first block, as second block (start clamped to 0) and alone: every decision and every DP
+    record is the oracle's."""
+    import random
+    import _cases
+    rng = random.Random(31)
+    scs = _l1cases.scenarios(611, 24)
+    odd = []
+    for variant in range(6):
+        core = _cases.rand_seq(rng, 2600)
+        core_s = _cases.mutate(rng, core, 0.01, 0.003, 0.003)
+        master = _cases.rand_seq(rng, rng.randint(0, 40)) + core + _cases.rand_seq(rng, 200)
+        slave = core_s + _cases.rand_seq(rng, 150)
+        off = len(master) - 200 - len(core)
+        normal = (off + 300, off + 620, 290, 615, "+", "+", 20)
+        normal2 = (off + 900, off + 1300, 890, 1290, "+", "+", 12)
+        empty = (off + 10, off + 200, 0, -1, "+", "+", 7)          # s_begin = 0, s_end = -1: an empty slave frame
+        empty_late = (off + 700, off + 800, 0, -1, "+", "+", 7)
+        blocks = [[empty, normal, normal2], [normal, empty_late, normal2], [empty], [empty, normal], [normal, normal2, empty_late],
+                  [(off + 10, off + 200, 5, 2, "+", "-", 9), normal]][variant]
+        odd.append(dict(kind="empty_frame", master=master, slave=slave, blocks=blocks, tails=(True, True, True, True)))
+    mixed = scs[:12] + odd + scs[12:]
+    stats = _check_against_oracle(ctx(), mixed)
+    assert stats["ok"] >= 5
+    # and on their own (no ordinary merge block in the call: no chain launch at all)
+    _check_against_oracle(ctx(), odd)
+
+
 def test_single_merge_block_calls_match_batched():
     c = ctx()
     scs = _l1cases.scenarios(77, 6)

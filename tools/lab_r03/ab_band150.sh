@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # A/B timing of the band-150 throughput kernels on the GPU box (diagnostics build): eight tasks per wavefront (two quads,
 # packed f16; default for >= 32 768 N-free tasks) against four (GAMDP_NO_PAIR=1); full / fill only / fill + strips
 mkdir -p gpurun_out/ab150

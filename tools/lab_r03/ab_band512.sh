@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # A/B timing of the band-512 kernels on the GPU box (diagnostics builds): two tasks per wavefront in packed f16 (default)
 # against one task per wavefront (GAMDP_NO_PAIR=1); full / fill only / fill + strips.  libgamdp_diag_w5.so = the pair
 # kernel compiled for 5 waves per SIMD (hand-built for this comparison; the host side still plans 4 per SIMD).

@@ -1,4 +1,8 @@
-# fill / fill + strips (diagnostics builds): tools/ab_fillmat.sh "<bench args>" libdiag1.so ...
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
+# fill / fill + strips (diagnostics builds): tools/lab_r03/ab_fillmat.sh "<bench args>" libdiag1.so ...
 ARGS="$1"; shift
 mkdir -p gpurun_out/abfm
 for lib in "$@"; do

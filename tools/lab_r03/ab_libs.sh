@@ -1,4 +1,8 @@
-# A/B of library builds on one workload: tools/ab_libs.sh "<bench args>" lib1.so lib2.so ...   ("-" = the product library)
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
+# A/B of library builds on one workload: tools/lab_r03/ab_libs.sh "<bench args>" lib1.so lib2.so ...   ("-" = the product library)
 ARGS="$1"; shift
 mkdir -p gpurun_out/ablibs
 for lib in "$@"; do

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # Band 150, eight tasks per wavefront: how much of the kernel is the tail of the last round?  100 000 tasks are 3.05 rounds
 # of 8 x 4 096; 98 304 are exactly 3.  Optional $1 = another build of the library to compare (e.g. 2-lane strips).
 mkdir -p gpurun_out/tail150

@@ -1,4 +1,8 @@
-# PMC comparison of library builds on one workload: tools/pmc_ab.sh "<bench args>" lib1.so lib2.so ...  ("-" = product)
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
+# PMC comparison of library builds on one workload: tools/lab_r03/pmc_ab.sh "<bench args>" lib1.so lib2.so ...  ("-" = product)
 ARGS="$1"; shift
 mkdir -p gpurun_out/pmcab
 export TMPDIR=/tmp

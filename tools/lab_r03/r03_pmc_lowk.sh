@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3: why a SIMD with one or two wavefronts runs the fill at 55-72 %: SQ counters of the fill alone (diagnostics build,
 # GAMDP_DIAG_SKIP_TRACEBACK) at 2048 pairs (1 wavefront per SIMD), 4096 (2) and 40960 (4, ten rounds)
 cd /tmp; export TMPDIR=/tmp

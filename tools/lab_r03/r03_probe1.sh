@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 1: issue rates at 1-4 wavefronts per SIMD (micro-benchmark 6) and the short-launch baseline of the library
 mkdir -p gpurun_out/r03_probe1
 ./tools/valu_rate6 > gpurun_out/r03_probe1/valu_rate6.log 2>&1

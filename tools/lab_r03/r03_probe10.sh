@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 10: the one-task band-150 kernel with direction-free fast blocks (default) and without (GAMDP_NO_DF5=1), where batches use it
 B="timeout -s KILL 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --no-proxy --band 150"
 run() { name=$1; shift; "$@" 2>&1 | python -c "

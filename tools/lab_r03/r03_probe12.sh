@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # A/B on one box: diagnostics builds with the packed stream before / after the reordering (alternating, two passes).
 # libgamdp_diag_oldpair.so = `make -C gam_ngs_amd/csrc variant NAME=oldpair` with kernel_pair.inc of the commit before (not kept in the tree).
 # Result: no difference beyond noise (13 105 - 13 116 / 10 430 - 10 820 / 10 440 - 10 500 GCUPS at 100 000 / 12 500 / 4 096 pairs, both).

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 13: what the int32 top blocks (pos <= 0 region) cost: windows from base 0 against windows from base 600 / 200
 B="timeout -s KILL 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150 --no-proxy"
 run() { name=$1; shift; "$@" 2>&1 | python -c "

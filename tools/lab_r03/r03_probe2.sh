@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 2: software-pipelined packed fill -- parity first, then the size sweep
 mkdir -p gpurun_out/r03_probe2
 timeout 900 python -m pytest tests/test_gpu_l0_parity.py tests/test_gpu_fullsize_properties.py -x -q -m gpu > gpurun_out/r03_probe2/pytest.log 2>&1; tail -3 gpurun_out/r03_probe2/pytest.log

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 3: where a wavefront's time goes at 1 and at 4 wavefronts per SIMD -- pipelined fill vs source order
 mkdir -p gpurun_out/r03_probe3
 for P in 2048 40960; do

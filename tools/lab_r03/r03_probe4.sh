@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 4: longest-remaining-first issue priority -- parity, then A/B at short launches (GAMDP_NO_PRIO=1 = off)
 mkdir -p gpurun_out/r03_probe4
 timeout 900 python -m pytest tests/test_gpu_l0_parity.py -x -q -m gpu -k "not fresh_process and not range_assertion" > gpurun_out/r03_probe4/pytest.log 2>&1; tail -3 gpurun_out/r03_probe4/pytest.log

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 5: is it the memory traffic of the packed fill that holds a SIMD with one or two wavefronts back?  (fill only)
 export GAMDP_DIAG_SKIP_TRACEBACK=1
 for lib in diag diag_nostore diag_nomem diag_src; do for P in 2048 4096 40960; do

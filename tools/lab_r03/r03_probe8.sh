@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 # round 3, probe 8: a lone wavefront on a band-150 call (what the longest chain of a merge-block launch is): fill vs walk
 mkdir -p gpurun_out/r03_probe8
 D=$PWD/gam_ngs_amd/libgamdp_diag.so

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (lab notes: how a number quoted in DESIGN.md was measured; run under gpurun from the repo root)
+set -eu
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT = the repo copy on the GPU box)}"
 mkdir -p gpurun_out/r02_sweep
 B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-l1 --no-band150"
 run() { name=$1; shift; $B "$@" > gpurun_out/r02_sweep/$name.log 2>&1; python - gpurun_out/r02_sweep/$name.log $name <<'PY'
