@@ -151,9 +151,16 @@ def measured_traffic(P_launch, length, band, launches_ok, kernel):
             except (OSError, KeyError, ValueError):
                 pass
     if best is None:
-        return None, None, None
+        return None, None, None, None
     name, tj = best
-    return tj["hbm_bytes_per_launch"], "profiles/" + name, tj.get("commit")
+    return tj["hbm_bytes_per_launch"], "profiles/" + name, tj.get("commit"), tj.get("source_hash")
+
+
+def source_hash():
+    """hash of the library's sources as this run sees them (tools/srchash.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import srchash
+    return srchash.source_hash(ROOT)
 
 
 PACKED_STREAM_CEILING_GCUPS = 20400.0   # tools/valu_rate5.hip: the bare packed-f16 cell stream on the whole chip
@@ -185,6 +192,7 @@ def valu_record(P_launch, length, band, kernel, gcups):
         cells = P_launch * (2 * band + 1) * length   # x_size * y_size per pair: the b window is the ~len-base slave
         rec["insts_per_cell"] = cj["counters"]["SQ_INSTS_VALU"] * 64.0 / cells
         rec["source"] = "profiles/%s @%s (SQ_INSTS_VALU x 64 lanes / cell updates of one launch)" % (name, tj.get("commit") or "unrecorded")
+        rec["profile_matches_source"] = tj.get("source_hash") == source_hash()
     return rec
 
 
@@ -270,6 +278,14 @@ def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
     rec = {"workload": "the same %d pairs at band 150" % P, "gcups": cells / dt / 1e9, "steps": steps, "ms_per_step": dt * 1e3,
            "kernel": kernel_name(band, P, length), "kernel_ms_per_launch": per_launch_s * 1e3, "launches": int(launches),
            "roofline_frac": (cells * steps / max(1, launches)) * B_ALG / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s > 0 else 0.0}
+    # counters of this workload, replayed from its committed profile set like the headline's (null when there is none)
+    tb, tsrc, tcommit, thash = measured_traffic(P, length, band, launches == steps, rec["kernel"])
+    rec["traffic"] = (tb / per_launch_s / 1e9) if tb and per_launch_s > 0 else None
+    rec["traffic_bytes_per_launch"] = tb
+    rec["traffic_over_algorithmic"] = (tb / (cells * steps / max(1, launches) * B_ALG)) if tb else None
+    rec["traffic_source"] = ("replayed from %s @%s" % (tsrc, tcommit or "unrecorded")) if tsrc else None
+    rec["profile_matches_source"] = (thash == source_hash()) if tsrc else None
+    rec["valu"] = valu_record(P, length, band, rec["kernel"], rec["gcups"])
     if verify:
         pos = strided_sample(P, verify)   # spread over the whole list (its order is also the launch's pairing order)
         ids = [m["first"] + k * m["stride"] for k in pos]
@@ -420,7 +436,7 @@ def main():
         cells_per_launch = m["cells_rank"] * steps / max(1, launches)
         achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         kname = kernel_name(args.band, m["P"], length)
-        traffic_bytes, traffic_src, traffic_commit = measured_traffic(m["P"], length, band, launches == steps, kname)
+        traffic_bytes, traffic_src, traffic_commit, traffic_hash = measured_traffic(m["P"], length, band, launches == steps, kname)
         line = {
             "metric": "GCUPS", "value": m["gcups"], "unit": "GCUPS", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": m["dt_max"] / steps * 1e3, "higher_is_better": True,
@@ -442,6 +458,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / avg_launch_s / 1e9) if traffic_bytes and avg_launch_s > 0 else None,
                          "traffic_bytes_per_launch": traffic_bytes, "traffic_measured_in_this_run": False,
+                         # were the replayed counters collected on the sources this run uses?  (a hash of gam_ngs_amd/csrc +
+                         # include/, recorded with every profile set: tools/srchash.py)
+                         "profile_matches_source": (traffic_hash == source_hash()) if traffic_src else None,
+                         "source_hash": source_hash(),
                          "traffic_source": ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                             "workload, collected at commit %s), divided by this run's kernel time"
                                             % (traffic_src, traffic_commit or "unrecorded")) if traffic_src else None,
@@ -483,7 +503,7 @@ def main():
                                                                   verify=0 if args.no_cpu_baseline else 128)
         if not args.no_l1 and world == 1:
             import bench_l1
-            line["l1"] = bench_l1.run(ctx, genome=args.l1_genome)
+            line["l1"] = bench_l1.run(ctx, genome=args.l1_genome, cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -38,7 +38,83 @@ def marshal(flat):
     return ins, keep
 
 
-def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150):
+B_ALG = 0.2507          # algorithmic HBM bytes per cell update
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(pb, flat, band):
+    """The CPU path beside it: the oracle's restatement of alignMergeBlock (oracle/gamdp_oracle.c, kind "port" -- PctgBuilder.cc
+    itself cannot be built here) on the SAME merge blocks, a pool of host threads pulling merge blocks from a shared list the
+    way ThreadedBuildPctg.cc:50-74 deals graphs.  At most ~600 M cells of it (the 2.9 Mb workload whole; a spread sample of a
+    bigger one), so that the default bench run stays within minutes.  Test infrastructure timed as a reported baseline,
+    never part of the product path."""
+    from concurrent.futures import ThreadPoolExecutor
+    import _gage
+    import _oracle as O
+    threads = min(os.cpu_count() or 1, 32)
+    n = len(flat)
+    budget = 600e6
+    order = list(range(n))
+    total = sum(sum(b[3] - b[2] + 1 for b in mb["blocks"]) * (2 * band + 1) for mb in flat)
+    step = max(1, int(total / budget + 0.999))
+    order = order[::step]
+    enc_m, enc_s = {}, {}
+    jobs = []
+    for i in order:
+        mb = flat[i]
+        if mb["m_id"] not in enc_m:
+            enc_m[mb["m_id"]] = O.encode(_gage.to_ascii(pb["master"][mb["m_id"]]["seq"]))
+        if mb["s_id"] not in enc_s:
+            enc_s[mb["s_id"]] = O.encode(_gage.to_ascii(pb["slave"][mb["s_id"]]["seq"]))
+        nb = len(mb["blocks"])
+        arr = (O.OracleBlock * max(1, nb))()
+        for k, b in enumerate(mb["blocks"]):
+            arr[k].m_begin, arr[k].m_end, arr[k].s_begin, arr[k].s_end = b[0], b[1], b[2], b[3]
+            arr[k].m_strand, arr[k].s_strand, arr[k].n_reads = b[4].encode(), b[5].encode(), b[6]
+        o = O.OracleMB()
+        o.m_ltail, o.m_rtail, o.s_ltail, o.s_rtail = [int(x) for x in mb["tails"]]
+        jobs.append((enc_m[mb["m_id"]], enc_s[mb["s_id"]], arr, nb, o))
+    fn = O.oracle().gamdp_oracle_align_merge_block
+
+    def one(j):
+        m, s, arr, nb, o = j
+        fn(m, len(m), s, len(s), arr, nb, band, C.byref(o), None, 0)   # (ctypes releases the GIL for the call)
+        return o.cells
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        t0 = time.perf_counter()
+        cells1 = sum(ex.map(one, jobs))
+        dt1 = time.perf_counter() - t0
+        # ~15 s of CPU work in all: the sample over and over (a pass of the 2.9 Mb workload is a tenth of a second on 32 threads)
+        reps = max(1, min(100, int(15.0 / max(dt1 * threads, 1e-3))))
+        t0 = time.perf_counter()
+        cells = 0
+        for _ in range(reps):
+            cells += sum(ex.map(one, jobs))
+        dt = time.perf_counter() - t0
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "merge_blocks_per_s": reps * len(jobs) / dt, "cores": threads, "kind": "port",
+            "sample": "%d of the %d merge blocks (every %d-th) x %d passes, %d threads, %.1f s" % (len(jobs), n, step, reps, threads, dt)}
+
+
+def replayed_counters(genome):
+    """PMC counters of the chain kernel for this workload from the newest committed profile set (profiles/*_l1_<w>_pmc_counters.json,
+    tools/collect_l1_profiles.sh): replayed, and labelled with the sources they were collected on."""
+    w = {2_900_000: "2p9mb", 30_000_000: "30mb"}.get(genome)
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if (w and os.path.isdir(pdir)) else []:
+        if name.endswith("_l1_%s_pmc_counters.json" % w):
+            best = name
+    if best is None:
+        return None
+    pj = json.load(open(os.path.join(pdir, best)))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import srchash
+    return {"source": "profiles/%s @%s" % (best, pj.get("commit") or "unrecorded"), "profile_matches_source": pj.get("source_hash") == srchash.source_hash(ROOT),
+            "hbm_bytes_per_launch": pj.get("hbm_bytes_per_launch"), "traffic_over_algorithmic": pj.get("traffic_over_algorithmic"),
+            "valu_insts_per_cell": pj.get("valu_insts_per_cell"), "measured_in_this_run": False}
+
+
+def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150, cpu=True):
     """Returns the "l1" object of the bench line.  `verify` merge blocks are checked against the CPU oracle's driver
     (oracle/, checker only) outside the timed region; a difference fails the run."""
     import _gage
@@ -83,7 +159,14 @@ def run(ctx, genome=2_900_000, steps=5, warmup=1, seed=1, verify=24, band=150):
         "host_pending_ms": acc["pend"] / steps, "host_feed_ms": acc["feed"] / steps,
         "rounds": int(st.rounds), "cohorts": int(st.cohorts), "launches": int(st.launches),
         "align_ok": sum(1 for i in range(n) if outs[i].align_ok), "setup_s": round(t_setup, 2),
+        # the HBM roofline of the whole call (0.2507 B per cell update against 8 TB/s) and of the time its kernels ran: a call
+        # lasts as long as its longest chain at a lone wavefront's speed, so both are tiny -- stated, not hidden
+        "roofline_frac": st.cells * B_ALG / dt / 1e9 / HBM_PEAK_GBS,
+        "roofline_frac_gpu_busy": (st.cells * B_ALG / (acc["busy"] / steps / 1e3) / 1e9 / HBM_PEAK_GBS) if acc["busy"] else None,
+        "counters": replayed_counters(genome),
     }
+    if cpu:
+        rec["cpu_baseline"] = cpu_baseline(pb, flat, band)
     if verify:
         from _l1oracle import oracle_mb
         # a sample across the whole size distribution (every (n-1)/(verify-1)-th merge block of the list sorted by block
@@ -117,6 +200,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verify", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     import gam_ngs_amd as gam
-    print(json.dumps(run(gam.Context(0), genome=a.genome, steps=a.steps, seed=a.seed, verify=a.verify)))
+    print(json.dumps(run(gam.Context(0), genome=a.genome, steps=a.steps, seed=a.seed, verify=a.verify, cpu=not a.no_cpu_baseline)))

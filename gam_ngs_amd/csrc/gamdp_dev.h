@@ -84,6 +84,9 @@ struct LaunchParams {
 // the two-task kernel walks its two tasks side by side (kernel_walk.inc) instead of one after the other: set by the host for
 // launches of at most two rounds, where the wavefronts of a SIMD walk at the same time and the scalar unit is the bottleneck
 constexpr u32 LP_WALK_SIDE_BY_SIDE = 1;
+// the packed kernels keep the int32 tagged code for their top blocks (cells with pos <= 0), as before round 4: GAMDP_NO_PACKED_TOP=1 (A/B,
+// and a second way through every test)
+constexpr u32 LP_NO_PACKED_TOP = 2;
 
 // Kernel variants.  C = band columns per lane; CE = (2*band) % C is the in-lane position of the
 // last band column (compile-time for the tuned variants, -1 = runtime for the generic ones).

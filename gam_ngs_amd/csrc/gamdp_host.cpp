@@ -710,6 +710,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
             static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::atol(e) : 2ull; }();
             p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
+            static const bool no_packed_top = std::getenv("GAMDP_NO_PACKED_TOP") != nullptr;
+            if (no_packed_top) p.flags |= LP_NO_PACKED_TOP;
             {   // longest-remaining-first issue priority for the units in flight when the queue runs dry (gamdp_dev.h)
                 static const bool no_prio = std::getenv("GAMDP_NO_PRIO") != nullptr;
                 const u64 tpw = (u64)kernel_tasks_per_wave(L.kid), units = L.count / tpw;

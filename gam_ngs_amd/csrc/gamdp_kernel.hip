@@ -70,7 +70,7 @@ __device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams&
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.df_lo = t.df_hi = 0;
+    t.df_lo = t.df_hi = t.df_top = 0;
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
         t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
@@ -179,7 +179,7 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.df_lo = t.df_hi = 0;
+    t.df_lo = t.df_hi = t.df_top = 0;
     t.prio_R = t.prio_nblk = 0;
     t.cancel = nullptr;
     const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
@@ -277,7 +277,7 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
     t.iA = __builtin_amdgcn_readlane(m.iA, src); t.eaRel = __builtin_amdgcn_readlane(m.eaRel, src);
     t.dir = rlp(m.dir, src); t.h0row = rlp(m.h0row, src); t.pos0 = rlp(m.pos0, src); t.lastrow = rlp(m.lastrow, src); t.adh = rlp(m.adh, src);
     t.ckpt = rlp(m.ckpt, src); t.bnd = rlp(m.bnd, src);
-    t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src);
+    t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src); t.df_top = __builtin_amdgcn_readlane(m.df_top, src);
     t.prio_R = t.prio_nblk = 0; t.cancel = nullptr;
     return t;
 }
@@ -353,7 +353,18 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     // ... followed, still packed, by the blocks up to where the first task leaves its fast + end run
     int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
-    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    // The top blocks (cells with pos <= 0: rows < band + 1 - begin_a) go packed as well when the two tasks share begin_a -- the
+    // pos == -1 cell is then the same cell (r, c) of a lane for both -- and neither is a force_start call: from the first group
+    // start behind the ramp (every lane past its row 1) and one tagged block, pair_top_range() up to the first plain block
+    int top_from = 0, top_to = 0;
+    if (GAMDP_PACKED_TOP && hi > lo && ta.begin_a == tb.begin_a && !ta.fs && !tb.fs && !(p.flags & LP_NO_PACKED_TOP)) {
+        const int after_ramp = (pa.LE + 1 + ROWS - 1) / ROWS;   // first block with tau0 - LE >= 1
+        top_from = (after_ramp + 1 + 3) & ~3;
+        top_to = max(pa.b0, pb.b0);                              // (equal: same begin_a, same band)
+        if (top_from < top_to && top_to <= lo) lo = top_from;
+        else top_from = top_to = 0;
+    }
+    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
     if (p.prio_R != 0 && qi >= p.prio_from) {
         ta.prio_R = tb.prio_R = (int)p.prio_R;
         ta.prio_nblk = tb.prio_nblk = max(pa.nblk, pb.nblk);
@@ -365,7 +376,9 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     init_row0<C, HASN, true>(&stb, &tb, lane);
     tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : pb.nblk, lane);
     if (hi > lo) {
-        pair_range<C, CE, false>(&sta, &stb, &ta, &tb, lo, mid, lane);
+        int from = lo;
+        if (top_to > top_from) { pair_top_range<C, CE>(&sta, &stb, &ta, &tb, top_from, top_to, lane); from = top_to; }
+        pair_range<C, CE, false>(&sta, &stb, &ta, &tb, from, mid, lane);
         if (hi > mid) pair_range<C, CE, true>(&sta, &stb, &ta, &tb, mid, hi, lane);
         single_resume<C, HASN, true>(&sta, &ta, hi, lane);
         tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane);
@@ -424,7 +437,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.df_lo = t.df_hi = 0;
+    t.df_lo = t.df_hi = t.df_top = 0;
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
         t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
@@ -532,7 +545,19 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     const int nA = quad_max(pa.nblk), nB = quad_max(pb.nblk);
     int lo = (quad_max(max(pa.b0, pb.b0)) + 1 + 3) & ~3, mid = quad_min(min(pa.b1, pb.b1)) & ~3, hi = quad_min(min(pa.b2, pb.b2)) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || quad_or((int)((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE))) lo = mid = hi = 0;
-    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi;
+    // packed top blocks (see run_pair): all eight tasks share begin_a, none is a force_start call
+    int top_from = 0, top_to = 0;
+    if (GAMDP_PACKED_TOP && hi > lo && !(p.flags & LP_NO_PACKED_TOP)) {
+        const int bmax = quad_max(max(ta.begin_a, tb.begin_a)), bmin = quad_min(min(ta.begin_a, tb.begin_a));
+        if (bmax == bmin && !quad_or((int)(ta.fs || tb.fs))) {
+            const int after_ramp = (uni(pa.LE) + 1 + ROWS - 1) / ROWS;
+            top_from = (after_ramp + 1 + 3) & ~3;
+            top_to = quad_max(max(pa.b0, pb.b0));
+            if (top_from < top_to && top_to <= lo) lo = top_from;
+            else top_from = top_to = 0;
+        }
+    }
+    ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
     if (p.prio_R != 0 && qi >= p.prio_from) {
         ta.prio_R = tb.prio_R = (int)p.prio_R;
         ta.prio_nblk = tb.prio_nblk = max(nA, nB);
@@ -544,7 +569,9 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     init_row0<C, HASN, true, QL>(&stb, &tb, lane);
     quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : nB, lane);
     if (hi > lo) {
-        pair_range<C, CE, false, QL>(&sta, &stb, &ta, &tb, lo, mid, lane);
+        int from = lo;
+        if (top_to > top_from) { pair_top_range<C, CE, QL>(&sta, &stb, &ta, &tb, top_from, top_to, lane); from = top_to; }
+        pair_range<C, CE, false, QL>(&sta, &stb, &ta, &tb, from, mid, lane);
         if (hi > mid) pair_range<C, CE, true, QL>(&sta, &stb, &ta, &tb, mid, hi, lane);
         single_resume<C, HASN, true, QL>(&sta, &ta, hi, lane);
         quad_tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, nA, lane);

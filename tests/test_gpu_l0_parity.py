@@ -233,7 +233,7 @@ def test_range_assertion_of_the_packed_blocks_in_the_diagnostics_build():
     for extra in ({}, {"GAMDP_QUAD_MIN": "1"}):
         env = dict(os.environ, GAMDP_LIB=DIAG_LIB, **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                            "adversarial_golden_vectors_through or golden_large or pairs_of_unequal or direction_free or band150_stress_cases"],
+                            "adversarial_golden_vectors_through or golden_large or pairs_of_unequal or direction_free or band150_stress_cases or packed_top_blocks"],
                            env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
 
@@ -447,6 +447,73 @@ def test_band150_stress_cases():
         assert r.ops == (ops if flags[k] else None), k
 
 
+def _top_block_batches():
+    """Batches built for the packed top blocks (pair_top_range): every call of a batch starts at the same begin_a -- 0, inside
+    the band's left triangle, at its edge, just past it (no top blocks at all) -- so that whichever two (eight) calls share a
+    wavefront qualify; windows on b, ends past the contigs, alignments whose path starts at pos == 0 far down the triangle
+    (a has a long prefix b lacks) or at row 0 far to the right (b has a long prefix a lacks), an early end of a.  Plus one
+    batch of mixed begin_a and one with force_start calls: those wavefronts keep the int32 top blocks."""
+    import _cases
+    rng = random.Random(4711)
+    batches = []
+    for band, begins in ((512, (0, 1, 37, 300, 511, 512, 513, 700)), (150, (0, 1, 37, 149, 150, 151, 400))):
+        for begin_a in begins:
+            cases = []
+            for k in range(8):
+                n = rng.choice((2600, 3100, 4100, 6100)) if band == 512 else rng.choice((900, 1300, 2100, 4100))
+                a, b = _cases.related_pair(rng, n)
+                kind = k % 4
+                if kind == 1:
+                    a = _cases.rand_seq(rng, rng.randint(40, band - 20)) + a      # the path enters at pos == 0, rows down the triangle
+                elif kind == 2:
+                    b = _cases.rand_seq(rng, rng.randint(40, band - 20)) + b      # the path enters in row 0, right of the band's centre
+                elif kind == 3:
+                    a = a[:len(a) - rng.randint(100, 600)]                         # a ends early: the end cell lies on the pos == end_a anti-diagonal
+                ba = min(begin_a, len(a) - 1)
+                bb = rng.choice((0, 0, 13, 250))
+                cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=len(a) - 1 + rng.choice((0, 0, 40)),
+                                  begin_b=bb, end_b=len(b) - 1 - rng.choice((0, 0, 7)), fs=False, fe=(k == 5)))
+            batches.append(cases)
+        mixed = []
+        for k in range(8):
+            a, b = _cases.related_pair(rng, 3300 if band == 512 else 1500)
+            mixed.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=(0, 5, 0, 90)[k % 4], end_a=len(a) - 1, begin_b=0,
+                              end_b=len(b) - 1, fs=(k >= 6), fe=False))
+        batches.append(mixed)
+    return batches
+
+
+def test_packed_top_blocks():
+    """The blocks that hold cells with pos <= 0 run packed too when the calls of a wavefront share begin_a (round 4,
+    kernel_pair.inc pair_top_range; banded_smith_waterman.cc:111-133,143-155 is what must survive: the pos == 0 rules, the
+    zero-initialised matrix left of it).  Against the oracle, summaries and edit strings; the band-150 batches reach the
+    eight-task kernel in the GAMDP_QUAD_MIN=1 child of test_four_tasks_per_wavefront_kernels, every batch the int32 top
+    blocks once more in the GAMDP_NO_PACKED_TOP=1 child below."""
+    n_ok = 0
+    for cases in _top_block_batches():
+        for want_ops in (False, True):
+            res = run_cases(cases, want_ops=want_ops)
+            for k, (cs, r) in enumerate(zip(cases, res)):
+                o, ops = oracle_for(cs, want_ops)
+                assert r.key() == o.key(), (cs["band"], cs["begin_a"], k, len(cs["a"]), r.key(), o.key())
+                assert (not want_ops) or r.ops == ops, (cs["band"], cs["begin_a"], k)
+                n_ok += o.status == 0
+    assert n_ok >= 150
+
+
+def test_int32_top_blocks_in_a_fresh_process():
+    """GAMDP_NO_PACKED_TOP=1: the packed kernels keep the int32 tagged code for their top blocks (the path of rounds 1-3,
+    still taken by wavefronts whose calls differ in begin_a or force their start): same results."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_NO_PACKED_TOP"):
+        pytest.skip("already inside the child")
+    env = dict(os.environ, GAMDP_NO_PACKED_TOP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "packed_top_blocks or golden_large or medium_pairs or pairs_of_unequal or adversarial_golden_vectors_through"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
 def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
     """GAMDP_QUAD_MIN=1 sends every band-150 call of a batch through the throughput kernels instead of only batches larger
     than the chip's wave slots: eight tasks per wavefront (two quads, fast blocks in packed f16) for contigs without N,
@@ -456,7 +523,7 @@ def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
     import os, subprocess, sys
     if os.environ.get("GAMDP_QUAD_MIN"):
         pytest.skip("already inside the four-task child")
-    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap"
+    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks"
     for extra in ({}, dict(GAMDP_NO_PAIR="1"), dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
         env = dict(os.environ, GAMDP_QUAD_MIN="1", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", sel],

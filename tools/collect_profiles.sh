@@ -14,6 +14,7 @@ EXTRA="$@"
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+python3 tools/srchash.py > $OUT/${TAG}_source_hash    # the sources these counters belong to (bench.py: profile_matches_source)
 if [ -z "$EXTRA" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-proxy > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
 else

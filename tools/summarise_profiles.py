@@ -10,6 +10,8 @@ pairs, length, band = (int(x) for x in (sys.argv[2:5] if len(sys.argv) >= 5 else
 want_kernel = sys.argv[5] if len(sys.argv) >= 6 else None   # e.g. "k_align_p<" : the dominant kernel of this workload
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(root, "tools"))
+import srchash
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
@@ -54,7 +56,11 @@ fetch = counters["FETCH_SIZE"] * 1024.0 * 2.0
 write = counters["WRITE_SIZE"] * 1024.0
 with open(os.path.join(dst, f"{tag}_traffic.json"), "w") as g:
     commit = open(os.path.join(src, f"{tag}_commit")).read().strip() if os.path.exists(os.path.join(src, f"{tag}_commit")) else None
-    json.dump({"round": int(tag[1:3]) if tag[1:3].isdigit() else None, "commit": commit, "kernel": kernel, "workload": {"pairs_per_launch": pairs, "len": length, "band": band},
+    # the sources the data was collected on: recorded by the collecting side (gpurun_out/<tag>_source_hash, written on the GPU
+    # box from the tree it ran) -- falls back to this tree, which is the same one when nothing was edited in between
+    hpath = os.path.join(src, f"{tag}_source_hash")
+    shash = open(hpath).read().strip() if os.path.exists(hpath) else srchash.source_hash(root)
+    json.dump({"round": int(tag[1:3]) if tag[1:3].isdigit() else None, "commit": commit, "source_hash": shash, "kernel": kernel, "workload": {"pairs_per_launch": pairs, "len": length, "band": band},
                "FETCH_SIZE_KB": counters["FETCH_SIZE"], "WRITE_SIZE_KB": counters["WRITE_SIZE"],
                "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --steps 1 --warmup 0 "
