@@ -361,7 +361,11 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
         const int after_ramp = (pa.LE + 1 + ROWS - 1) / ROWS;   // first block with tau0 - LE >= 1
         top_from = (after_ramp + 1 + 3) & ~3;
         top_to = max(pa.b0, pb.b0);                              // (equal: same begin_a, same band)
-        if (top_from < top_to && top_to <= lo) lo = top_from;
+        // ... top blocks and nothing else: a call whose end_a lies inside the band's first rows has its pos == end_a anti-diagonal
+        // (an END capture) in the same blocks
+        bool only_top = top_from < top_to && top_to <= lo;
+        for (int b = top_from; only_top && b < top_to; ++b) only_top = plan_mode(pa, b) == M_TOP && plan_mode(pb, b) == M_TOP;
+        if (only_top) lo = top_from;
         else top_from = top_to = 0;
     }
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
@@ -553,7 +557,9 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
             const int after_ramp = (uni(pa.LE) + 1 + ROWS - 1) / ROWS;
             top_from = (after_ramp + 1 + 3) & ~3;
             top_to = quad_max(max(pa.b0, pb.b0));
-            if (top_from < top_to && top_to <= lo) lo = top_from;
+            int only_top = (top_from < top_to && top_to <= lo) ? 1 : 0;
+            for (int b = top_from; only_top && b < top_to; ++b) only_top = quad_or((plan_mode(pa, b) != M_TOP || plan_mode(pb, b) != M_TOP) ? 1 : 0) ? 0 : 1;
+            if (only_top) lo = top_from;
             else top_from = top_to = 0;
         }
     }

@@ -183,3 +183,26 @@ def adversarial_specs():
 def adversarial_case(kind, n, band):
     a, b = adversarial_pair(kind, n, band)
     return dict(a=a.encode(), b=b.encode(), band=band, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False)
+
+
+def window_cases(seed, band, count=60):
+    """Random windowed cases of 0.6 - 14 kb for the direction-free / packed kernels of one band (tools/parity_band512.py and
+    tests/test_gpu_l0_parity.py::test_window_cases_on_long_pairs): lengths such that the direction-free range is empty, one
+    group, a few groups ...; partners of a wavefront of very different length; begin_a = 0 half the time (wavefronts that
+    share it run their top blocks packed), anywhere else otherwise; end_a anywhere from begin_a to past the end of a (an
+    early end_a puts the pos == end_a anti-diagonal into the top blocks); windows on b; force flags; N in a third."""
+    rng = random.Random(5120 + seed)
+    cases = []
+    for _ in range(count):
+        n = rng.choice([600, 900, 1300, 2000, 3000, 5000, 8000, 14000])
+        a = rand_seq(rng, n, 0.002 if rng.random() < 0.3 else 0.0)
+        b = mutate(rng, a[rng.randint(0, 200):], 0.03, rng.choice([0.0, 0.01, 0.03]), rng.choice([0.0, 0.01, 0.03]))
+        if not b:
+            b = "A"
+        ba = rng.choice([0, 0, rng.randint(0, 700), rng.randint(0, n - 1)])
+        ea = rng.choice([n - 1, n - 1, rng.randint(ba, n + 600)])
+        bb = rng.choice([0, 0, rng.randint(0, min(300, len(b) - 1))])
+        eb = rng.choice([len(b) - 1, len(b) - 1, rng.randint(bb, len(b) + 50)])
+        cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb,
+                          fs=rng.random() < 0.2, fe=rng.random() < 0.2))
+    return cases

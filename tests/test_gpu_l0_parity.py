@@ -233,7 +233,7 @@ def test_range_assertion_of_the_packed_blocks_in_the_diagnostics_build():
     for extra in ({}, {"GAMDP_QUAD_MIN": "1"}):
         env = dict(os.environ, GAMDP_LIB=DIAG_LIB, **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                            "adversarial_golden_vectors_through or golden_large or pairs_of_unequal or direction_free or band150_stress_cases or packed_top_blocks"],
+                            "adversarial_golden_vectors_through or golden_large or pairs_of_unequal or direction_free or band150_stress_cases or packed_top_blocks or window_cases"],
                            env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
 
@@ -474,6 +474,15 @@ def _top_block_batches():
                 cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=len(a) - 1 + rng.choice((0, 0, 40)),
                                   begin_b=bb, end_b=len(b) - 1 - rng.choice((0, 0, 7)), fs=False, fe=(k == 5)))
             batches.append(cases)
+        # end_a inside the band's first rows: the pos == end_a anti-diagonal (an END capture) runs through the top blocks, which then
+        # stay int32 (parity_band512.py found the packed version of this, round 4)
+        early = []
+        for k in range(8):
+            a, b_ = _cases.related_pair(rng, 2600 if band == 512 else 1400)
+            ea = rng.choice((band // 2, band, band + 20, 2 * band + 7))
+            early.append(dict(a=a.encode(), b=b_.encode(), band=band, begin_a=0, end_a=ea, begin_b=rng.choice((0, 46)), end_b=len(b_) - 1 - rng.choice((0, 79)),
+                              fs=False, fe=False))
+        batches.append(early)
         mixed = []
         for k in range(8):
             a, b = _cases.related_pair(rng, 3300 if band == 512 else 1500)
@@ -501,6 +510,33 @@ def test_packed_top_blocks():
     assert n_ok >= 150
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_window_cases_on_long_pairs(seed):
+    """tests/_cases.py window_cases (the generator of tools/parity_band512.py): random windows on 0.6 - 14 kb pairs at band 512,
+    with and without edit strings -- begin_a shared or not, end_a early or late, force flags, N; seed 2 also with a scratch arena
+    of a handful of slots.  (Seed 2 holds the call that found round 4's packed top blocks taking a pos == end_a anti-diagonal
+    along: begin_a 0, end_a 532, 1 875 rows.)  Band 150 runs the same in the GAMDP_QUAD_MIN=1 child."""
+    band = 150 if _os.environ.get("GAMDP_QUAD_MIN") else 512
+    cases = _cases.window_cases(seed, band)
+    c = ctx()
+    if seed == 2:
+        c.set_arena_bytes(40 << 20)
+    try:
+        n = 0
+        for want_ops in (False, True):
+            res = run_cases(cases, want_ops=want_ops)
+            for k, (cs, r) in enumerate(zip(cases, res)):
+                o, ops = oracle_for(cs, want_ops)
+                if o.status == O.INVALID:
+                    continue
+                n += 1
+                assert r.key() == o.key(), (seed, k, {x: v for x, v in cs.items() if x not in ("a", "b")}, len(cs["a"]), len(cs["b"]), r.key(), o.key())
+                assert (not want_ops) or r.ops == ops, (seed, k)
+        assert n >= 100
+    finally:
+        c.set_arena_bytes(0)
+
+
 def test_int32_top_blocks_in_a_fresh_process():
     """GAMDP_NO_PACKED_TOP=1: the packed kernels keep the int32 tagged code for their top blocks (the path of rounds 1-3,
     still taken by wavefronts whose calls differ in begin_a or force their start): same results."""
@@ -509,7 +545,7 @@ def test_int32_top_blocks_in_a_fresh_process():
         pytest.skip("already inside the child")
     env = dict(os.environ, GAMDP_NO_PACKED_TOP="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "packed_top_blocks or golden_large or medium_pairs or pairs_of_unequal or adversarial_golden_vectors_through"],
+                        "packed_top_blocks or window_cases or golden_large or medium_pairs or pairs_of_unequal or adversarial_golden_vectors_through"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
 
@@ -523,7 +559,7 @@ def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
     import os, subprocess, sys
     if os.environ.get("GAMDP_QUAD_MIN"):
         pytest.skip("already inside the four-task child")
-    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks"
+    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks or window_cases"
     for extra in ({}, dict(GAMDP_NO_PAIR="1"), dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
         env = dict(os.environ, GAMDP_QUAD_MIN="1", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", sel],

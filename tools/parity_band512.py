@@ -20,20 +20,7 @@ def main():
     n_total = 0
     band = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
-        rng = random.Random(5120 + seed)
-        cases = []
-        for _ in range(60):
-            n = rng.choice([600, 900, 1300, 2000, 3000, 5000, 8000, 14000])
-            a = _cases.rand_seq(rng, n, 0.002 if rng.random() < 0.3 else 0.0)
-            b = _cases.mutate(rng, a[rng.randint(0, 200):], 0.03, rng.choice([0.0, 0.01, 0.03]), rng.choice([0.0, 0.01, 0.03]))
-            if not b:
-                b = "A"
-            ba = rng.choice([0, 0, rng.randint(0, 700), rng.randint(0, n - 1)])
-            ea = rng.choice([n - 1, n - 1, rng.randint(ba, n + 600)])
-            bb = rng.choice([0, 0, rng.randint(0, min(300, len(b) - 1))])
-            eb = rng.choice([len(b) - 1, len(b) - 1, rng.randint(bb, len(b) + 50)])
-            cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb,
-                              fs=rng.random() < 0.2, fe=rng.random() < 0.2))
+        cases = _cases.window_cases(seed, band)
         if seed % 3 == 2:
             _gpu.ctx().set_arena_bytes(40 << 20)   # a handful of slots
         for want_ops in (False, True):
