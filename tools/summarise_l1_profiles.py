@@ -19,7 +19,7 @@ for w in ("2p9mb", "30mb"):
     bench = json.loads(lines[-1])
     counters, launches = {}, {}
     for name in ("fetch", "write", "sq"):
-        hits = sorted(glob.glob(os.path.join(src, f"{tag}_l1_{w}_{name}/**/*_counter_collection.csv"), recursive=True))
+        hits = sorted(glob.glob(os.path.join(src, f"{tag}_l1_{w}_{name}/**/*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
         if not hits:
             continue
         with open(hits[-1]) as f:

@@ -16,7 +16,7 @@ src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)   # (a re-collected tag: the newest run)
     if not hits:
         raise SystemExit("missing " + pattern)
     return hits[-1]
