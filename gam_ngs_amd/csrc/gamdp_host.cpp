@@ -894,11 +894,16 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     cc[0]->arena_div = cc[1]->arena_div = 2;
     cc[0]->trim_scratch(); cc[1]->trim_scratch();
     cc[1]->kernel_ms = 0; cc[1]->kernel_launches = 0;
-    const size_t pieces = 4, per = (n + pieces - 1) / pieces;
+    // Four pieces, the first one small: nothing runs on the GPU until the first piece is validated, sorted and staged, and
+    // that costs ~5 ms per 100 000 tasks -- so the first piece is an eighth of the batch (GAMDP_CHUNK_FIRST_DIV), the other three
+    // share the rest; the second thread prepares piece 1 meanwhile.
+    static const size_t first_div = [] { const char* e = std::getenv("GAMDP_CHUNK_FIRST_DIV"); const long v = e ? std::atol(e) : 8; return (size_t)std::max(4L, v); }();
+    const size_t pieces = 4, n0 = n / first_div, per = (n - n0 + 2) / 3;
+    size_t bound[5] = {0, n0, std::min(n, n0 + per), std::min(n, n0 + 2 * per), n};
     int rc[2] = {0, 0};
     auto worker = [&](int t) noexcept {
         for (size_t k = (size_t)t; k < pieces && rc[t] == 0; k += 2) {
-            const size_t first = k * per, cnt = first < n ? std::min(per, n - first) : 0;
+            const size_t first = bound[k], cnt = bound[k + 1] - bound[k];
             if (cnt) rc[t] = guarded(cc[t], [&] { return run(cc[t], first, cnt); });
         }
     };
