@@ -866,10 +866,12 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     // whole batch would sit in front of / behind the kernel (25 ms of a 120 ms step for 400 000 5 kb pairs).  They go
     // through in four pieces on two host threads with a context (stream, staging, arena) each: one piece's host work
     // runs while the other's kernel does.  Results do not depend on the split.
-    // (From 65 536 calls on when the calls are small -- under ~12 M cell updates each by their windows: 10 kb at band 512, any
-    // length up to 40 kb at band 150 -- since the first piece is small (below): 200 000 x 5 kb at band 512 9 110 -> 10 020 GCUPS;
-    // from 262 144 on whatever their size.  Long calls in fewer than that stay whole: four short launches would lose more at
-    // their ends than the host work they hide.  GAMDP_CHUNK_MIN=n: from n calls on, whatever their size.)
+    // (From 65 536 calls on when the calls are small -- by their windows under ~12 M cell updates each, 7 M at band 150 whose
+    // eight-task wavefronts hold eight direction images per scratch slot: 11 kb at band 512, 23 kb at band 150 -- since the
+    // first piece is small (below): 200 000 x 5 kb at band 512 9 110 -> 9 780 GCUPS; from 262 144 on whatever their size.  Long
+    // calls in fewer than that stay whole: the two contexts share the scratch arena, and four short launches would lose more
+    // at their ends than the host work they hide (100 000 x 50 kb in pieces: 2.5 s per step).  GAMDP_CHUNK_MIN=n: from n calls
+    // on, whatever their size.)
     static const long chunk_env = [] { const char* e = std::getenv("GAMDP_CHUNK_MIN"); return e ? (long)std::atoll(e) : -1L; }();
     bool chunked = chunk_env >= 0 ? n >= (size_t)chunk_env : n >= 262144;
     if (!chunked && chunk_env < 0 && n >= 65536) {
@@ -879,7 +881,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
             const gamdp_task& t = tasks[i];
             est += (t.end_b >= t.begin_b ? (double)std::min<u64>(t.end_b - t.begin_b + 1, 500000) : 0.0) * (2.0 * t.band + 1.0);
         }
-        chunked = est / (double)std::max<size_t>(1, cnt) < 12e6;
+        chunked = est / (double)std::max<size_t>(1, cnt) < (tasks[0].band == 150 ? 7e6 : 12e6);
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor
