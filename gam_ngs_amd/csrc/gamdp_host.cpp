@@ -868,13 +868,13 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     // runs while the other's kernel does.  Results do not depend on the split.
     // (From 65 536 calls on when the calls are small -- by their windows under ~12 M cell updates each, 7 M at band 150 whose
     // eight-task wavefronts hold eight direction images per scratch slot: 11 kb at band 512, 23 kb at band 150 -- since the
-    // first piece is small (below): 200 000 x 5 kb at band 512 9 110 -> 9 780 GCUPS; from 262 144 on whatever their size.  Long
-    // calls in fewer than that stay whole: the two contexts share the scratch arena, and four short launches would lose more
+    // first piece is small (below): 200 000 x 5 kb at band 512 9 110 -> 9 780 GCUPS.  Batches of long calls stay whole whatever
+    // their number: the two contexts share the scratch arena, and four short launches would lose more
     // at their ends than the host work they hide (100 000 x 50 kb in pieces: 2.5 s per step).  GAMDP_CHUNK_MIN=n: from n calls
     // on, whatever their size.)
     static const long chunk_env = [] { const char* e = std::getenv("GAMDP_CHUNK_MIN"); return e ? (long)std::atoll(e) : -1L; }();
-    bool chunked = chunk_env >= 0 ? n >= (size_t)chunk_env : n >= 262144;
-    if (!chunked && chunk_env < 0 && n >= 65536) {
+    bool chunked = chunk_env >= 0 && n >= (size_t)chunk_env;
+    if (chunk_env < 0 && n >= 65536) {
         double est = 0;   // (a sample of the windows is enough: every 64th call)
         size_t cnt = 0;
         for (size_t i = 0; i < n; i += 64, cnt++) {

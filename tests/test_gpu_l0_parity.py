@@ -357,7 +357,7 @@ def test_two_task_kernel_with_one_after_the_other_walks_in_a_fresh_process():
 
 
 def test_pieces_over_two_contexts_in_a_fresh_process():
-    """Batches of >= 262 144 calls go through in four pieces on two host threads / contexts (host work of one piece hidden
+    """Batches of >= 65 536 small calls go through in four pieces on two host threads / contexts (host work of one piece hidden
     behind the other's kernel); GAMDP_CHUNK_MIN=16 applies that to the small batches of this file: same results."""
     import os, subprocess, sys
     if os.environ.get("GAMDP_CHUNK_MIN"):
