@@ -87,6 +87,9 @@ constexpr u32 LP_WALK_SIDE_BY_SIDE = 1;
 // the packed kernels keep the int32 tagged code for their top blocks (cells with pos <= 0), as before round 4: GAMDP_NO_PACKED_TOP=1 (A/B,
 // and a second way through every test)
 constexpr u32 LP_NO_PACKED_TOP = 2;
+// the strips of the direction-free ranges begin at multiples of the strip width, as before round 4 (Tk::sshift = 0): GAMDP_NO_STRIP_SHIFT=1
+// (A/B, and a second way through the tests)
+constexpr u32 LP_NO_STRIP_SHIFT = 4;
 
 // Kernel variants.  C = band columns per lane; CE = (2*band) % C is the in-lane position of the
 // last band column (compile-time for the tuned variants, -1 = runtime for the generic ones).

@@ -712,6 +712,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
             static const bool no_packed_top = std::getenv("GAMDP_NO_PACKED_TOP") != nullptr;
             if (no_packed_top) p.flags |= LP_NO_PACKED_TOP;
+            static const bool no_strip_shift = std::getenv("GAMDP_NO_STRIP_SHIFT") != nullptr;
+            if (no_strip_shift) p.flags |= LP_NO_STRIP_SHIFT;
             {   // longest-remaining-first issue priority for the units in flight when the queue runs dry (gamdp_dev.h)
                 static const bool no_prio = std::getenv("GAMDP_NO_PRIO") != nullptr;
                 const u64 tpw = (u64)kernel_tasks_per_wave(L.kid), units = L.count / tpw;

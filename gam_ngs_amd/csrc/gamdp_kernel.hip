@@ -53,6 +53,47 @@ __shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise
 #include "kernel_strip.inc"
 #include "kernel_finish.inc"
 
+// block modes of one task (scalar) and its runs: b0 = first fast block, b1 = first block after that fast run
+struct Plan { int nblk, b0, b1, b2; int64_t iE0, iE1; int X, LE, begin_a, w; };  // b2 = first block after the end run that follows
+__device__ __forceinline__ int plan_mode(const Plan& pl, const int blk)
+{
+    const int tau0 = blk * ROWS;
+    const bool top = !((tau0 - pl.LE >= 1) && ((int64_t)pl.begin_a - pl.w + tau0 >= 1));
+    const bool end = !((tau0 + ROWS - 1 < pl.X - 1) && ((int64_t)(tau0 + ROWS - 1) < pl.iE0 || (int64_t)(tau0 - pl.LE) > pl.iE1));
+    return (top ? M_TOP : 0) | (end ? M_END : 0);
+}
+template <int C>
+__device__ __forceinline__ Plan make_plan(const Tk& t)
+{
+    Plan pl;
+    pl.X = t.X; pl.w = t.band; pl.begin_a = t.begin_a; pl.LE = (t.Y - 1) / C;
+    pl.nblk = (t.X - 1 + pl.LE) / ROWS + 1;
+    pl.iE0 = t.end_a - t.begin_a - t.band; pl.iE1 = t.end_a - t.begin_a + t.band;
+    // b0 / b1 / b2 in closed form (a scan over the blocks was 2 x 3 000 iterations of per-lane 64-bit compares for the eight 50 kb
+    // tasks of a wavefront): blocks are top blocks below bt; not end blocks in [0, nA) (before the pos == end_a anti-diagonal
+    // enters the band and before the last row) and in [sB, eB) (after it has left) -- nA <= sB, eB <= nblk.
+    const int64_t nb = pl.nblk;
+    const int64_t T0 = max((int64_t)pl.LE + 1, (int64_t)pl.w - pl.begin_a + 1);
+    const int64_t bt = min((T0 + ROWS - 1) / ROWS, nb);
+    const int64_t M = min((int64_t)pl.X - 1, pl.iE0);
+    const int64_t nA = M > 0 ? min(M / ROWS, nb) : 0;
+    const int64_t eB = pl.X - 1 > 0 ? (int64_t)((pl.X - 1) / ROWS) : 0;
+    const int64_t S = pl.iE1 + pl.LE;
+    const int64_t sB = S >= 0 ? min(S / ROWS + 1, nb) : 0;
+    int64_t b0, b1, b2;
+    if (bt < nA) {
+        b0 = bt; b1 = nA;
+        const int64_t s = max(sB, nA);
+        b2 = s < eB ? s : nb;
+    } else {
+        const int64_t s = max(bt, sB);
+        if (s < eB) { b0 = s; b1 = eB; b2 = nb; }
+        else b0 = b1 = b2 = nb;
+    }
+    pl.b0 = (int)b0; pl.b1 = (int)b1; pl.b2 = (int)b2;
+    return pl;
+}
+
 // ---- the whole task -------------------------------------------------------------------------------
 // phases A and B: row 0 and the sweep; leaves the task's values in t for the end-cell search and the walk
 template <int C, int CE, bool HASN>
@@ -70,7 +111,8 @@ __device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams&
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.df_lo = t.df_hi = t.df_top = 0;
+    t.df_lo = t.df_hi = t.df_top = t.sshift = 0;
+    if constexpr (DIRFREE_OK<CE, C, HASN>) t.sshift = (p.flags & LP_NO_STRIP_SHIFT) ? 0 : strip_shift<C, Strip<64>::SL>(dt.band);
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
         t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
@@ -98,14 +140,9 @@ __device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams&
         // the first run of fast blocks goes direction-free, in whole groups of 4 blocks, leaving at least one tagged
         // fast block in front (what a lane receives at a group start must be its neighbour's plain last column)
         if (p.ckpt_off != 0 && !(dt.flags & TF_LIVE_MASK & TF_NO_DIRFREE)) {
-            int b0 = 0;
-            while (b0 < nblk && mode_of(b0) != M_FAST) ++b0;
-            int b1 = b0;
-            while (b1 < nblk && mode_of(b1) == M_FAST) ++b1;
-            int b2 = b1;  // the end blocks that follow run direction-free too, as far as whole groups go
-            while (b2 < nblk && mode_of(b2) == M_END) ++b2;
-            const int lo = (b0 + 1 + 3) & ~3, hi = b2 & ~3;
-            if (hi - lo >= 8 && b1 > lo) { t.df_lo = lo; t.df_hi = hi; }
+            const Plan pl = make_plan<C>(t);   // b2: the end blocks that follow the fast run go direction-free too, as far as whole groups go
+            const int lo = (pl.b0 + 1 + 3) & ~3, hi = pl.b2 & ~3;
+            if (hi - lo >= 8 && pl.b1 > lo) { t.df_lo = lo; t.df_hi = hi; }
         }
     }
     for (int blk = 0; blk < nblk;) {
@@ -179,7 +216,7 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
     t.adh = t.lastrow + p.ypad;
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
-    t.df_lo = t.df_hi = t.df_top = 0;
+    t.df_lo = t.df_hi = t.df_top = t.sshift = 0;
     t.prio_R = t.prio_nblk = 0;
     t.cancel = nullptr;
     const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
@@ -188,32 +225,6 @@ __device__ __forceinline__ Tk make_tk(const DevTask& dt, const LaunchParams& p, 
     const int64_t ia = ge ? t.end_a - ((int64_t)t.begin_a + t.band) : 0;
     t.iA = (int)min(ia, (int64_t)(1 << 30));
     return t;
-}
-
-// block modes of one task (scalar) and its runs: b0 = first fast block, b1 = first block after that fast run
-struct Plan { int nblk, b0, b1, b2; int64_t iE0, iE1; int X, LE, begin_a, w; };  // b2 = first block after the end run that follows
-__device__ __forceinline__ int plan_mode(const Plan& pl, const int blk)
-{
-    const int tau0 = blk * ROWS;
-    const bool top = !((tau0 - pl.LE >= 1) && ((int64_t)pl.begin_a - pl.w + tau0 >= 1));
-    const bool end = !((tau0 + ROWS - 1 < pl.X - 1) && ((int64_t)(tau0 + ROWS - 1) < pl.iE0 || (int64_t)(tau0 - pl.LE) > pl.iE1));
-    return (top ? M_TOP : 0) | (end ? M_END : 0);
-}
-template <int C>
-__device__ __forceinline__ Plan make_plan(const Tk& t)
-{
-    Plan pl;
-    pl.X = t.X; pl.w = t.band; pl.begin_a = t.begin_a; pl.LE = (t.Y - 1) / C;
-    pl.nblk = (t.X - 1 + pl.LE) / ROWS + 1;
-    pl.iE0 = t.end_a - t.begin_a - t.band; pl.iE1 = t.end_a - t.begin_a + t.band;
-    int b0 = 0;
-    while (b0 < pl.nblk && plan_mode(pl, b0) != M_FAST) ++b0;
-    int b1 = b0;
-    while (b1 < pl.nblk && plan_mode(pl, b1) == M_FAST) ++b1;
-    int b2 = b1;
-    while (b2 < pl.nblk && plan_mode(pl, b2) == M_END) ++b2;
-    pl.b0 = b0; pl.b1 = b1; pl.b2 = b2;
-    return pl;
 }
 
 // blocks [from, to) of one task with the int32 tagged code (directions for every cell)
@@ -277,7 +288,7 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
     t.iA = __builtin_amdgcn_readlane(m.iA, src); t.eaRel = __builtin_amdgcn_readlane(m.eaRel, src);
     t.dir = rlp(m.dir, src); t.h0row = rlp(m.h0row, src); t.pos0 = rlp(m.pos0, src); t.lastrow = rlp(m.lastrow, src); t.adh = rlp(m.adh, src);
     t.ckpt = rlp(m.ckpt, src); t.bnd = rlp(m.bnd, src);
-    t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src); t.df_top = __builtin_amdgcn_readlane(m.df_top, src);
+    t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src); t.df_top = __builtin_amdgcn_readlane(m.df_top, src); t.sshift = __builtin_amdgcn_readlane(m.sshift, src);
     t.prio_R = t.prio_nblk = 0; t.cancel = nullptr;
     return t;
 }
@@ -347,6 +358,7 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     u32* const sideA = slot + 2 * p.dir_words;
     Tk ta = make_tk(da, p, slot, sideA, slot);
     Tk tb = make_tk(db, p, slot + p.dir_words, sideA + 4u * p.ypad, slot);
+    ta.sshift = tb.sshift = (p.flags & LP_NO_STRIP_SHIFT) ? 0 : strip_shift<C, Strip<64, true>::SL>(max(ta.band, tb.band));
     const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);
     // the packed range: fast blocks of BOTH tasks, whole groups of 4 blocks, at least one tagged fast block in front of it
     // for either task (what a lane receives at a group start must be its neighbour's plain last column)
@@ -442,6 +454,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     t.ckpt = (gptr)(slot + p.ckpt_off);
     t.bnd = (gptr)(slot + p.bnd_off);
     t.df_lo = t.df_hi = t.df_top = 0;
+    t.sshift = (p.flags & LP_NO_STRIP_SHIFT) ? 0 : strip_shift<C, Strip<LPT>::SL>(uni(quad_max(dt.band)));   // one for the wavefront: its lanes share the boundary slots
     {
         const int64_t rel = t.end_a - t.begin_a + t.band;  // may be negative
         t.eaRel = (int)min(max(rel, (int64_t)-(1 << 30)), (int64_t)(1 << 30));
@@ -470,14 +483,9 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
     // run_task), whole groups of 4 blocks, up to where the first task leaves its fast + end run
     int e_min = 0;
     if (p.ckpt_off != 0 && !(dt.flags & TF_LIVE_MASK & TF_NO_DIRFREE)) {
-        int b0 = 0;
-        while (b0 < nblk && mode_of(b0) != M_FAST) ++b0;
-        int b1 = b0;
-        while (b1 < nblk && mode_of(b1) == M_FAST) ++b1;
-        int b2 = b1;
-        while (b2 < nblk && mode_of(b2) == M_END) ++b2;
-        const int lo = quad_max((b0 + 1 + 3) & ~3), hi = quad_min(b2 & ~3);
-        e_min = quad_min(b1);
+        const Plan pl = make_plan<C>(t);   // per lane
+        const int lo = quad_max((pl.b0 + 1 + 3) & ~3), hi = quad_min(pl.b2 & ~3);
+        e_min = quad_min(pl.b1);
         if (hi - lo >= 8 && e_min > lo) { t.df_lo = lo; t.df_hi = hi; }
     }
     const int df_lo = t.df_lo, df_hi = t.df_hi;  // wave-uniform by construction
@@ -545,6 +553,7 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     const long long tf0 = wall_clock64();
     g_exp_mat_ticks = 0;
 #endif
+    ta.sshift = tb.sshift = (p.flags & LP_NO_STRIP_SHIFT) ? 0 : strip_shift<C, Strip<QL, true>::SL>(uni(quad_max(max(ta.band, tb.band))));   // one for the wavefront
     const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);   // per lane
     const int nA = quad_max(pa.nblk), nB = quad_max(pb.nblk);
     int lo = (quad_max(max(pa.b0, pb.b0)) + 1 + 3) & ~3, mid = quad_min(min(pa.b1, pb.b1)) & ~3, hi = quad_min(min(pa.b2, pb.b2)) & ~3;
