@@ -206,3 +206,25 @@ def window_cases(seed, band, count=60):
         cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=ea, begin_b=bb, end_b=eb,
                           fs=rng.random() < 0.2, fe=rng.random() < 0.2))
     return cases
+
+
+def displaced_path_cases(band, seed=0, n=5200):
+    """Pairs whose alignment runs parallel to the main diagonal of the band, k columns off it, for k from one band edge to the
+    other (b = a copy of a[k:], or k unrelated bases in front of a copy of a): a path in every strip of the direction-free
+    kernels, the first and the last lane of a task included (strips that begin sshift lanes before a multiple of their width
+    have lanes there that belong to the neighbouring task or to nobody).  A third of the pairs carries N."""
+    rng = random.Random(7700 + 31 * band + seed)
+    ks = sorted(set([0, 1, 2, band - 1, band - 2, band - 3, band - 9, band - 20, band - 39] + [rng.randint(3, band - 3) for _ in range(7)]))
+    cases = []
+    for k in ks:
+        if k < 0 or k >= band:
+            continue
+        for sign in (1, -1):
+            a = rand_seq(rng, n + k, 0.002 if rng.random() < 0.33 else 0.0)
+            if sign > 0:
+                b = mutate(rng, a[k:], 0.02, 0.002, 0.002)
+            else:
+                b = rand_seq(rng, k) + mutate(rng, a, 0.02, 0.002, 0.002)
+            cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1,
+                              fs=False, fe=False))
+    return cases

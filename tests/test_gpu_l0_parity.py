@@ -537,6 +537,39 @@ def test_window_cases_on_long_pairs(seed):
         c.set_arena_bytes(0)
 
 
+def test_paths_in_every_strip():
+    """tests/_cases.py displaced_path_cases: alignments that run k columns off the middle of the band, from one band edge to the
+    other -- every strip of the direction-free kernels gets a walk, the strips at the two edges of a task (whose outer lanes
+    belong to the next task or to nobody since the strips are centred on the band's middle column, Tk::sshift) included.
+    Band 512 here; band 150 reaches the eight-task and the four-task kernels in the GAMDP_QUAD_MIN=1 children; the strips
+    of rounds 1-3 (GAMDP_NO_STRIP_SHIFT=1) in the child below."""
+    band = 150 if _os.environ.get("GAMDP_QUAD_MIN") else 512
+    cases = _cases.displaced_path_cases(band)
+    n = 0
+    for want_ops in (False, True):
+        res = run_cases(cases, want_ops=want_ops)
+        for k, (cs, r) in enumerate(zip(cases, res)):
+            o, ops = oracle_for(cs, want_ops)
+            assert r.key() == o.key(), (band, k, len(cs["a"]), len(cs["b"]), r.key(), o.key())
+            assert (not want_ops) or r.ops == ops, (band, k)
+            n += o.status == 0
+    assert n >= 50
+
+
+def test_strips_at_multiples_of_their_width_in_a_fresh_process():
+    """GAMDP_NO_STRIP_SHIFT=1: the strips of the direction-free ranges begin at multiples of the strip width (rounds 1-3):
+    same results, at band 512 and, through GAMDP_QUAD_MIN=1, in the eight-task kernel."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_NO_STRIP_SHIFT"):
+        pytest.skip("already inside the child")
+    for extra in ({}, dict(GAMDP_QUAD_MIN="1")):
+        env = dict(os.environ, GAMDP_NO_STRIP_SHIFT="1", **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                            "paths_in_every_strip or window_cases or golden_large or medium_pairs"],
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (extra, r.stdout[-2500:] + r.stderr[-2000:])
+
+
 def test_int32_top_blocks_in_a_fresh_process():
     """GAMDP_NO_PACKED_TOP=1: the packed kernels keep the int32 tagged code for their top blocks (the path of rounds 1-3,
     still taken by wavefronts whose calls differ in begin_a or force their start): same results."""
@@ -559,7 +592,7 @@ def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
     import os, subprocess, sys
     if os.environ.get("GAMDP_QUAD_MIN"):
         pytest.skip("already inside the four-task child")
-    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks or window_cases"
+    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks or window_cases or paths_in_every_strip"
     for extra in ({}, dict(GAMDP_NO_PAIR="1"), dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
         env = dict(os.environ, GAMDP_QUAD_MIN="1", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", sel],
