@@ -43,7 +43,8 @@ struct DevTask {
 enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4,
              TF_DIAG_SKIP_TRACEBACK = 8 /* timing diagnostics only (GAMDP_DIAG_SKIP_TRACEBACK=1): results invalid */,
              TF_NO_DIRFREE = 16 /* GAMDP_DIAG_NO_DIRFREE=1: keep directions in every block (A/B measurements) */,
-             TF_DIAG_COUNT_MAT = 32 /* GAMDP_DIAG_COUNT_MAT=1: n_match := number of materialise() calls (results invalid) */ };
+             TF_DIAG_COUNT_MAT = 32 /* GAMDP_DIAG_COUNT_MAT=1: n_match := number of materialise() calls (results invalid) */,
+             TF_PADDING = 64 /* a copy of a companion that fills a wavefront of the multi-task kernels: filled along, no end cell, no walk, no result */ };
 
 // the diagnostics flags only exist in the -DGAMDP_DIAG build: the product kernels mask them off at compile time, so a
 // stray flag (or environment variable) can neither skip the traceback nor overwrite result fields with counters

@@ -727,9 +727,13 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     }
     for (size_t li = 0; li < launches.size(); li++) {
         const std::vector<u32>& cur = launch_items[li];
-        DevTask* dst = h_tasks + launches[li].first;
+        const Launch& L = launches[li];
+        DevTask* dst = h_tasks + L.first;
         parallel_for(cur.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) dst[k] = prep[cur[k]].dt; });
-        for (size_t k = cur.size(); k < launches[li].count; k++) { dst[k] = dst[cur.size() - 1]; dst[k].res_idx = (u32)n; dst[k].flags &= ~(u32)TF_WANT_OPS; }
+        // the last wavefront of a multi-task launch: filled up with copies of its last call that are filled along and nothing else
+        auto pad = [&](size_t k, const DevTask& of) { dst[k] = of; dst[k].res_idx = (u32)n; dst[k].flags = (dst[k].flags & ~(u32)TF_WANT_OPS) | TF_PADDING; };
+        size_t k = cur.size();
+        for (; k < L.count; k++) pad(k, dst[cur.size() - 1]);
     }
     if (!launches.empty()) {
         u64 need_scratch = 0;
@@ -804,9 +808,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         if (ops_total) HIPCHK(this, hipMemcpyAsync(hops.data(), d_ops, ops_total, hipMemcpyDeviceToHost, stream));
         HIPCHK(this, hipStreamSynchronize(stream));
         const double ms_gpu = since(t_gpu);
-        if (diag_timing)
+        if (diag_timing) {
             std::fprintf(stderr, "libgamdp align: %zu tasks, %zu launches: prepare %.2f ms, plan+stage %.2f ms, upload+kernels+download %.2f ms\n",
                          n, launches.size(), ms_prep, ms_plan, ms_gpu);
+        }
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }

@@ -306,15 +306,22 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
         else return bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
     };
     WalkCarry wcs[NT];
-    int skip = 0;
+    int skip = 0, padding = 0;
 #ifdef GAMDP_EXP_PHASES
     const long long tp0 = wall_clock64();
 #endif
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
+        const u32 fl = (u32)uni((int)p.tasks[first_task + (u32)s].flags);
+        if (s > 0 && (fl & TF_PADDING)) {   // (never the first task of a wavefront: its end_cell() holds the barrier and the fence the others rely on)
+            WalkCarry w = {};
+            w.mat_q = w.old_q = -1; w.mat_hi = w.old_hi = -1;   // status 0: nothing to walk
+            wcs[s] = w;
+            padding |= 1 << s;
+            continue;
+        }
         const Tk ts = task_tk(s);
         end_cell<C>(&ts, lane, &wcs[s]);
-        const u32 fl = (u32)uni((int)p.tasks[first_task + (u32)s].flags);
         if (fl & TF_WANT_OPS) skip |= 1 << s;                                                   // the edit string takes one step at a time
         if (fl & TF_LIVE_MASK & (TF_DIAG_SKIP_TRACEBACK | TF_DIAG_COUNT_MAT)) skip |= (1 << NT) - 1;  // diagnostics: the one-task walk only
     }
@@ -332,6 +339,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
 #endif
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
+        if ((padding >> s) & 1) continue;
         const Tk ts = task_tk(s);
         const int lb = (LPT == 64) ? 0 : QL * (s & 3), hs = (LPT == 64) ? s : s >> 2;
         finish_walk<C, CE, HASN, LPT, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);

@@ -570,6 +570,38 @@ def test_strips_at_multiples_of_their_width_in_a_fresh_process():
         assert r.returncode == 0, (extra, r.stdout[-2500:] + r.stderr[-2000:])
 
 
+def test_wavefronts_filled_up_with_copies():
+    """The last wavefront of a multi-task launch is filled up with copies of its last call (TF_PADDING: filled along, no end cell, no
+    walk, no result).  301 short N-free band-150 calls through the eight-task kernel (GAMDP_QUAD_MIN=1 child) on a scratch arena of a
+    dozen slots -- several rounds, the last wavefront five copies --, and 3 calls alone (one wavefront, five copies); every call
+    against the oracle, with and without edit strings."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_TEST_PADDING_CHILD"):
+        rng = random.Random(4242)
+        cases = []
+        for k in range(301):
+            a, b = _cases.related_pair(rng, rng.choice([700, 1100, 1600, 2500]))
+            cases.append(dict(a=a.encode(), b=b.encode(), band=150, begin_a=rng.choice([0, 0, 3]), end_a=len(a) - 1, begin_b=0,
+                              end_b=len(b) - 1, fs=False, fe=False))
+        c = ctx()
+        c.set_arena_bytes(24 << 20)
+        try:
+            for batch in (cases, cases[:3]):
+                for want_ops in (False, True):
+                    res = run_cases(batch, want_ops=want_ops)
+                    for k, (cs, r) in enumerate(zip(batch, res)):
+                        o, ops = oracle_for(cs, want_ops)
+                        assert r.key() == o.key(), (k, len(cs["a"]), r.key(), o.key())
+                        assert (not want_ops) or r.ops == ops, k
+        finally:
+            c.set_arena_bytes(0)
+        return
+    env = dict(os.environ, GAMDP_QUAD_MIN="1", GAMDP_TEST_PADDING_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "wavefronts_filled_up"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
 def test_int32_top_blocks_in_a_fresh_process():
     """GAMDP_NO_PACKED_TOP=1: the packed kernels keep the int32 tagged code for their top blocks (the path of rounds 1-3,
     still taken by wavefronts whose calls differ in begin_a or force their start): same results."""
