@@ -91,6 +91,16 @@ constexpr u32 LP_NO_PACKED_TOP = 2;
 // the strips of the direction-free ranges begin at multiples of the strip width, as before round 4 (Tk::sshift = 0): GAMDP_NO_STRIP_SHIFT=1
 // (A/B, and a second way through the tests)
 constexpr u32 LP_NO_STRIP_SHIFT = 4;
+// Issue priority of a wavefront of the two- / eight-task kernels while it is in its end-cell / strip / walk phase: bits 8-9.  That phase
+// is latency (the walk: a memory round trip per diagonal run) and short dependent chains (a strip's tagged cells); at the level of the
+// fills beside it, it waits for issue slots on top of its own latencies and holds its slot -- and the three fills' only partner that
+// does something else -- for longer.  One level above a steady-state fill (the host sets 1 for launches of more than two rounds;
+// the units in flight when the queue runs dry are at 1..3 by remaining work and still go first): 100 000 x 50 kb at band 150
+// 170.7 -> 163.2 ms on one box, 170.0 -> 168.0 on another; band 512 359.5 -> 355.3; 200 000 x 5 kb at band 512 +4 %; level 2 and 3 gain
+// less, a level of its own for the walk proper changes nothing; launches of one or two rounds lose 1 % and stay at 0.  GAMDP_WALK_PRIO=0..3
+// overrides (A/B).  (The four-task int32 kernel, whose walks run one task at a time on the scalar unit, loses 3 % that way and the
+// one-task kernels gain nothing: they keep level 0.)
+constexpr u32 LP_WALK_PRIO_SHIFT = 8;
 
 // Kernel variants.  C = band columns per lane; CE = (2*band) % C is the in-lane position of the
 // last band column (compile-time for the tuned variants, -1 = runtime for the generic ones).

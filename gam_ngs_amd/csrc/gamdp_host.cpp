@@ -791,6 +791,12 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             if (no_packed_top) p.flags |= LP_NO_PACKED_TOP;
             static const bool no_strip_shift = std::getenv("GAMDP_NO_STRIP_SHIFT") != nullptr;
             if (no_strip_shift) p.flags |= LP_NO_STRIP_SHIFT;
+            {   // the end-cell / strip / walk phase of the two- and eight-task kernels issues one level above a steady-state fill in
+                // launches of more than two rounds (gamdp_dev.h; GAMDP_WALK_PRIO=0..3 overrides, A/B)
+                static const int walk_prio = [] { const char* e = std::getenv("GAMDP_WALK_PRIO"); return e ? std::atoi(e) & 3 : -1; }();
+                const u64 units = L.count / (u64)kernel_tasks_per_wave(L.kid);
+                p.flags |= (walk_prio >= 0 ? (u32)walk_prio : (units > 2ull * L.n_slots ? 1u : 0u)) << LP_WALK_PRIO_SHIFT;
+            }
             {   // longest-remaining-first issue priority for the units in flight when the queue runs dry (gamdp_dev.h)
                 static const bool no_prio = std::getenv("GAMDP_NO_PRIO") != nullptr;
                 const u64 tpw = (u64)kernel_tasks_per_wave(L.kid), units = L.count / tpw;

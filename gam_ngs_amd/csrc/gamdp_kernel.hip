@@ -415,7 +415,7 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
 #ifdef GAMDP_EXP_HWID
     const long long exp_t1 = wall_clock64();
 #endif
-    if (ta.prio_R != 0) __builtin_amdgcn_s_setprio(0);
+    if (ta.prio_R != 0 || (p.flags >> LP_WALK_PRIO_SHIFT) != 0) set_prio_level((p.flags >> LP_WALK_PRIO_SHIFT) & 3u);
     finish_many<C, CE, HASN, true, 2, 64>(p, 2 * qi, ta, tb, lane, (p.flags & LP_WALK_SIDE_BY_SIDE) != 0);
 #ifdef GAMDP_EXP_HWID
     // placement experiment (results unusable): task A's record carries when the pair started and when its fill ended
@@ -437,6 +437,7 @@ __global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_p(const
         if (lane == 0) qi = atomicAdd(p.cursor, 1u);
         qi = __builtin_amdgcn_readfirstlane(qi);
         if (2 * qi >= p.n_tasks) break;   // n_tasks is even (the host pads the last pair)
+        if ((p.flags >> LP_WALK_PRIO_SHIFT) != 0) __builtin_amdgcn_s_setprio(0);
         run_pair<C, CE>(p, qi, slot, lane);
     }
 }
@@ -519,7 +520,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
             ++blk;
         }
     }
-    if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);
+    if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);   // (the four-task kernel's walks, one task at a time on the scalar unit, lose 3 % one level up: LP_WALK_PRIO_SHIFT is for the packed kernels)
     finish_many<C, CE, HASN, false, QT>(p, 4 * qi, t, t, lane);
 }
 
@@ -604,7 +605,7 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
 #ifdef GAMDP_EXP_PHASES
     const long long tf1 = wall_clock64();
 #endif
-    if (uni(ta.prio_R) != 0) __builtin_amdgcn_s_setprio(0);
+    if (uni(ta.prio_R) != 0 || (p.flags >> LP_WALK_PRIO_SHIFT) != 0) set_prio_level((p.flags >> LP_WALK_PRIO_SHIFT) & 3u);
     finish_many<C, CE, HASN, true, 2 * QT>(p, 8 * qi, ta, tb, lane);
 #ifdef GAMDP_EXP_PHASES
     if (lane == 0) p.results[p.tasks[8 * qi].res_idx].begin_a = (int)(tf1 - tf0);
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(64, GAMDP_PAIR_WAVES_PER_SIMD) void k_align_o(const
         if (lane == 0) qi = atomicAdd(p.cursor, 1u);
         qi = __builtin_amdgcn_readfirstlane(qi);
         if (8 * qi >= p.n_tasks) break;   // n_tasks is a multiple of 8 (the host pads the last wavefront)
+        if ((p.flags >> LP_WALK_PRIO_SHIFT) != 0) __builtin_amdgcn_s_setprio(0);
         run_octo<C, CE>(p, qi, slot, lane);
     }
 }
