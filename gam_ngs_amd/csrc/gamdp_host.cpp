@@ -23,6 +23,7 @@
 #include "gamdp.h"
 #include "gamdp_dev.h"
 #include "gamdp_internal.h"
+#include "gamdp_hostpool.h"
 
 namespace gamdp {
 
@@ -337,81 +338,7 @@ static int pick_kernel(int band, bool has_n)
     return K_GEN_C17;
 }
 
-// fn(lo, hi) over [0, n) on up to 16 host threads (batches of a few thousand tasks are not worth a thread).
-// The threads are the process's own and stay: starting and joining 15 threads cost a parallel loop 0.5 - 0.8 ms, four
-// loops per batch call.  One parallel loop at a time -- a second caller (another context's thread) runs its loop itself.
-class HostPool {
-public:
-    static HostPool& get() { static HostPool p; return p; }
-    template <class F>
-    void run(size_t n, F& fn)
-    {
-        std::unique_lock<std::mutex> one(use_, std::try_to_lock);
-        if (!one.owns_lock() || workers_.empty()) { fn((size_t)0, n); return; }
-        const unsigned parts = (unsigned)workers_.size() + 1;
-        auto body = [&](unsigned k) { fn(n * k / parts, n * (k + 1) / parts); };
-        {
-            std::lock_guard<std::mutex> g(m_);
-            job_ = [&body](unsigned k) { body(k); };
-            parts_ = parts; next_ = 0; done_ = 0; ++epoch_;
-        }
-        cv_work_.notify_all();
-        work();   // the caller takes parts too
-        std::unique_lock<std::mutex> g(m_);
-        cv_done_.wait(g, [&] { return done_ == parts_; });
-        job_ = nullptr;
-    }
-private:
-    HostPool()
-    {
-        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        try { for (unsigned k = 1; k < hw; k++) workers_.emplace_back([this] { loop(); }); } catch (...) {}   // fewer threads, or none: still correct
-    }
-    ~HostPool()
-    {
-        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
-        cv_work_.notify_all();
-        for (auto& t : workers_) if (t.joinable()) t.join();
-    }
-    void work()
-    {
-        for (;;) {
-            unsigned k;
-            std::function<void(unsigned)> job;
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (!job_ || next_ >= parts_) return;
-                k = next_++;
-                job = job_;
-            }
-            job(k);
-            bool last;
-            { std::lock_guard<std::mutex> g(m_); last = ++done_ == parts_; }
-            if (last) cv_done_.notify_all();
-        }
-    }
-    void loop()
-    {
-        u64 seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_work_.wait(g, [&] { return stop_ || epoch_ != seen; });
-                if (stop_) return;
-                seen = epoch_;
-            }
-            work();
-        }
-    }
-    std::mutex use_, m_;
-    std::condition_variable cv_work_, cv_done_;
-    std::vector<std::thread> workers_;
-    std::function<void(unsigned)> job_;
-    unsigned parts_ = 0, next_ = 0, done_ = 0;
-    u64 epoch_ = 0;
-    bool stop_ = false;
-};
-
+// fn(lo, hi) over [0, n) on the process's host thread pool (gamdp_internal.h: HostPool); batches of a few thousand tasks are not worth a thread
 template <class F>
 static void parallel_for(size_t n, F fn)
 {
