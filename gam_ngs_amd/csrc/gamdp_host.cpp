@@ -518,15 +518,18 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // wavefront eat what the fill gains (measured: 400 000 x 2 kb pairs 15 % slower, 5 kb equal, 20 kb 8 % faster)
             u64 rows = 0;
             for (u32 i : g) rows += (u64)prep[i].dt.X;
-            // without N and with enough tasks to fill the chip eight at a time: two quads per wavefront, packed f16 (from
+            // without N and with enough tasks to fill the chip eight at a time: two quads per wavefront, packed f16 (round 3: from
             // ~4 k rows on: 400 000 x 5 kb pairs measured 5 % faster than one task per wavefront, 9 % faster than four)
             // ... and, for long contigs, from 6 144 tasks on: more than the one-task kernel holds in one round (5 120), and a
             // sparsely filled eight-task launch beats both its second round and the four-task int32 kernel (50 kb pairs:
             // 6 144 tasks 19.3 against 24.1 ms, 16 384 tasks 32.1 against 41.4 ms (four-task kernel), 4 096 tasks 18.6 against 12.3)
+            // (round 4, with the top blocks packed and the strips centred on the band's middle column: from ~1.5 k rows on -- 400 000 x 2 kb
+            // 4 450 -> 5 500 GCUPS, x 3 kb 4 980 -> 6 200, x 1 kb 3 300 against 3 100 the other way; GAMDP_OCTO_MIN_ROWS overrides, A/B)
+            static const size_t octo_min_rows = [] { const char* e = std::getenv("GAMDP_OCTO_MIN_ROWS"); return e ? (size_t)std::atol(e) : (size_t)1536; }();
             const size_t avg_rows = rows / g.size(), full = 8 * (size_t)n_cu * (size_t)kernel_waves_per_cu(K_O19_CE15);
             const bool octo = v == 0 && !no_pair150 && !diag_no_dirfree &&
                               (quad_min >= 0 ? g.size() >= (size_t)quad_min
-                                             : ((g.size() >= full && avg_rows >= 4096) || (g.size() >= 6144 && avg_rows >= 8192)));
+                                             : ((g.size() >= full && avg_rows >= octo_min_rows) || (g.size() >= 6144 && avg_rows >= 8192)));
             if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
             const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
             const u64 C = (u64)kernel_cols(to);
