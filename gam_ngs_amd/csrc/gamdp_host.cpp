@@ -526,10 +526,12 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // (round 4, with the top blocks packed and the strips centred on the band's middle column: from ~1.5 k rows on -- 400 000 x 2 kb
             // 4 450 -> 5 500 GCUPS, x 3 kb 4 980 -> 6 200, x 1 kb 3 300 against 3 100 the other way; GAMDP_OCTO_MIN_ROWS overrides, A/B)
             static const size_t octo_min_rows = [] { const char* e = std::getenv("GAMDP_OCTO_MIN_ROWS"); return e ? (size_t)std::atol(e) : (size_t)1536; }();
-            const size_t avg_rows = rows / g.size(), full = 8 * (size_t)n_cu * (size_t)kernel_waves_per_cu(K_O19_CE15);
+            // ... and from 12 288 calls on, not only from a chip-full of eight-task wavefronts (32 768): 16 384 x 5 kb 6.0 -> 5.0 ms, 24 576 x 5 kb
+            // 8.7 -> 7.3, 16 384 x 2.5 kb 3.8 - 4.9 -> 3.7 - 3.8; 8 192 x 5 kb: equal
+            const size_t avg_rows = rows / g.size();
             const bool octo = v == 0 && !no_pair150 && !diag_no_dirfree &&
                               (quad_min >= 0 ? g.size() >= (size_t)quad_min
-                                             : ((g.size() >= full && avg_rows >= octo_min_rows) || (g.size() >= 6144 && avg_rows >= 8192)));
+                                             : ((g.size() >= 12288 && avg_rows >= octo_min_rows) || (g.size() >= 6144 && avg_rows >= 8192)));
             if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
             const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
             const u64 C = (u64)kernel_cols(to);
