@@ -95,6 +95,7 @@ int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, 
     fwd.resize(n);
     rc.assign(n, DevSeq{nullptr, nullptr});
     has_n.assign(n, 0);
+    npre.assign(n, std::vector<u32>());
     u64 total = 0;
     std::vector<u64> at(n);
     for (u32 i = 0; i < n; i++) {
@@ -112,6 +113,12 @@ int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, 
             anyn |= (c == 4);
         }
         has_n[i] = anyn;
+        if (anyn) {
+            std::vector<u32>& pre = npre[i];
+            pre.assign((size_t)(lens[i] + 255) / 256 + 1, 0);
+            for (u64 k = 0; k < lens[i]; k++) pre[(size_t)(k / 256) + 1] += (codes[i][k] == 4);
+            for (size_t k = 1; k < pre.size(); k++) pre[k] += pre[k - 1];
+        }
         pack_into(codes[i].data(), lens[i], false, h2.data(), hn.data(), at[i]);
     }
     HIPCHK(ctx, hipMalloc(&d2, h2.size() * sizeof(u32)));
@@ -392,7 +399,21 @@ static int prepare_task(const ITask& it, Prepared& pr)
     if (st != GAMDP_ST_OK) return st;
     const u64 Y = 2 * band + 1;
     // GAMDP_DIAG_FORCE_N (diagnostics build only): run N-free inputs through the N-aware kernels as well
-    const bool has_n = diag().force_n || it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
+    // N by window, not by contig: the DP touches a[begin_a - band .. begin_a + X - 1 + band] and b[begin_b .. begin_b + X - 1] (pos =
+    // begin_a - band + x + y, banded_smith_waterman.cc:135-171), the walk stays inside them; 64 bases of margin on either side.
+    // GAMDP_N_BY_CONTIG=1: the contig's flag decides, as before round 4 (A/B, and a second way through the tests).
+    static const bool n_by_contig = std::getenv("GAMDP_N_BY_CONTIG") != nullptr;
+    bool has_n = diag().force_n;
+    if (!has_n && n_by_contig) has_n = it.sa->has_n[it.a_id] || it.sb->has_n[it.b_id];
+#ifdef GAMDP_DIAG
+    // fault injection (diagnostics build): windows too small by this many bases on either side -- the test of the windows must notice
+    static const int64_t margin = 64 - [] { const char* e = std::getenv("GAMDP_DIAG_N_WINDOW_SHRINK"); return e ? (int64_t)std::atol(e) : (int64_t)0; }();
+#else
+    constexpr int64_t margin = 64;
+#endif
+    if (!has_n && !n_by_contig)
+        has_n = it.sa->window_has_n(it.a_id, it.a_rc, it.a_off, (int64_t)it.begin_a - (int64_t)band - margin, (int64_t)it.begin_a + (int64_t)X - 1 + (int64_t)band + margin) ||
+                it.sb->window_has_n(it.b_id, it.b_rc, it.b_off, (int64_t)it.begin_b - margin, (int64_t)it.begin_b + (int64_t)X - 1 + margin);
     pr.kid = pick_kernel((int)band, has_n);
     const int C = kernel_cols(pr.kid);
     const int LE = (int)((Y - 1) / (u64)C);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -41,6 +42,21 @@ struct SeqSet {
     std::vector<std::vector<uint8_t>> codes;  // empty for packed-only sets (gamdp_seqset_create_synth)
     std::vector<u64> lens;
     std::vector<uint8_t> has_n;
+    // N by window: npre[i][k] = number of N among bases [0, 256 k) of sequence i, forward orientation (empty for a sequence without N)
+    std::vector<std::vector<u32>> npre;
+    // may bases [lo, hi] of the view (reverse complement or not, chopped by `off` bases) hold an N?  Positions outside the sequence
+    // do not count; the answer is by blocks of 256 bases, i.e. "yes" a little more often than the truth.
+    bool window_has_n(u32 id, bool rc, u64 off, int64_t lo, int64_t hi) const
+    {
+        if (!has_n[id]) return false;
+        if (id >= npre.size() || npre[id].empty()) return true;   // no counts kept: the contig's flag decides
+        const int64_t len = (int64_t)lens[id];
+        int64_t o_lo = (int64_t)off + std::max<int64_t>(lo, 0), o_hi = std::min<int64_t>((int64_t)off + hi, len - 1);
+        if (o_lo > o_hi) return false;
+        const int64_t f_lo = rc ? len - 1 - o_hi : o_lo, f_hi = rc ? len - 1 - o_lo : o_hi;
+        const std::vector<u32>& pre = npre[id];
+        return pre[(size_t)(f_hi / 256) + 1] != pre[(size_t)(f_lo / 256)];
+    }
     std::vector<DevSeq> fwd;
     mutable std::vector<DevSeq> rc;  // reverse complements, uploaded on first use
     mutable std::vector<u32*> rc_allocs;

@@ -262,6 +262,103 @@ def test_reverse_complement_and_suffix_views():
     assert r.key() == o.key() and r.ops == ops
 
 
+def _n_edge_cases(band):
+    """(a, b, begin_a, end_a, begin_b, end_b) with ONE N placed around each edge of what the DP touches: a[begin_a - band ..
+    begin_a + rows - 1 + band] and b[begin_b .. begin_b + rows - 1].  Two shapes: the alignment runs along the band's first column
+    (b is a copy of a from begin_a - band + 1 on) or along its last (a copy from begin_a + band - 1 on), so that the first / last
+    bases of the a range are ON the path; an N there scores 0 where the A in its place in the 2-bit plane would score +5 or -4."""
+    rng = random.Random(8800 + band)
+    out = []
+    rows = 700
+    for shape in ("low", "high"):
+        begin_a = band + 50 if shape == "low" else 40
+        shift = -band + 1 if shape == "low" else band - 1          # b[x] pairs with a[begin_a + shift + x]
+        a0 = _cases.rand_seq(rng, begin_a + shift + rows + band + 700)
+        b0 = a0[begin_a + shift: begin_a + shift + rows + 350]     # b is longer than the window on it
+        begin_b, end_b = 0, rows - 1
+        first_a, last_a = begin_a - band, begin_a + rows - 1 + band    # the a range the DP touches
+        spots = [("a", first_a + d) for d in (-400, -321, -257, -66, -65, -64, -2, -1, 0, 1, 2, 3, 9)] + \
+                [("a", last_a + d) for d in (-9, -3, -2, -1, 0, 1, 2, 63, 64, 65, 66, 257, 321, 400)] + \
+                [("b", end_b + d) for d in (-2, -1, 0, 1, 2, 64, 65, 66, 257, 300)] + [("b", d) for d in (0, 1, 2)]
+        for which, p in spots:
+            a, b = list(a0), list(b0)
+            tgt = a if which == "a" else b
+            if p < 0 or p >= len(tgt):
+                continue
+            tgt[p] = "N"
+            out.append(("".join(a).encode(), "".join(b).encode(), begin_a, len(a) - 1, begin_b, end_b, (shape, which, p - (first_a if which == "a" else 0))))
+    return out
+
+
+def test_one_n_around_every_edge_of_the_window():
+    """The N-aware kernels are chosen by the WINDOW a call touches, not by the contig (gamdp_host.cpp prepare_task, SeqSet::window_has_n):
+    one N at every distance around the first and the last base the DP touches on a, and around the window on b, with the alignment
+    running along the band's first / last column so that those bases are on the path -- a window computed too small would send the
+    call to an N-free kernel, which reads an A there.  Plain views, reverse-complement views and chopped views; band 150 (in the
+    GAMDP_QUAD_MIN=1 children the four- / eight-task kernels) and band 512; against the oracle."""
+    c = ctx()
+    for band in ((150,) if _os.environ.get("GAMDP_QUAD_MIN") else (150, 512)):
+        cases = _n_edge_cases(band)
+        seqs, calls, want = [], [], []
+        for k, (a, b, ba, ea, bb, eb, tag) in enumerate(cases):
+            ca, cb = api.encode(a), api.encode(b)
+            mode = k % 3
+            if mode == 0:      # plain
+                seqs += [ca, cb]
+                view = dict()
+            elif mode == 1:    # the set holds the reverse complements: the call asks for the rc view, which is a and b again
+                seqs += [api.reverse_complement(ca), api.reverse_complement(cb)]
+                view = dict(rc=True)
+            else:              # the set holds 37 / 11 more bases in front: the call chops them off
+                seqs += [api.encode(b"ACGTN" * 7 + b"AC") + ca, api.encode(b"GNNTACGTACG") + cb]
+                view = dict(off=(37, 11))
+            calls.append((len(seqs) - 2, view, ba, ea, bb, eb))
+            want.append(O.oracle_align(ca, cb, band, ba, ea, bb, eb))
+        sset = gam.SequenceSet(c, seqs, ascii=False)
+        bsw = gam.BandedSmithWaterman(c, band)
+        args = []
+        for i, view, ba, ea, bb, eb in calls:
+            if "rc" in view:
+                A, B = sset.contig(i, rc=True), sset.contig(i + 1, rc=True)
+            elif "off" in view:
+                A, B = sset.contig(i, off=view["off"][0]), sset.contig(i + 1, off=view["off"][1])
+            else:
+                A, B = sset.contig(i), sset.contig(i + 1)
+            args.append((A, ba, ea, B, bb, eb))
+        res = bsw.find_alignments(args, want_ops=True)
+        for k, (r, (o, ops)) in enumerate(zip(res, want)):
+            assert r.key() == o.key(), (band, cases[k][6], k % 3, r.key(), o.key())
+            assert r.ops == ops, (band, cases[k][6], k % 3)
+        sset.close()
+
+
+def test_a_window_too_small_is_noticed():
+    """Fault injection (diagnostics build, GAMDP_DIAG_N_WINDOW_SHRINK): with the windows 66 + 256 bases too small on either side -- past
+    the margin and the granularity of the N counts -- the test above must fail: it is the one that would catch a wrong window."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_DIAG_N_WINDOW_SHRINK"):
+        pytest.skip("already inside the child")
+    env = dict(os.environ, GAMDP_LIB=DIAG_LIB, GAMDP_DIAG_N_WINDOW_SHRINK=str(64 + 2 + 256))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "one_n_around"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "AssertionError" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
+    env = dict(os.environ, GAMDP_LIB=DIAG_LIB)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "one_n_around"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+
+
+def test_n_by_contig_in_a_fresh_process():
+    """GAMDP_N_BY_CONTIG=1: a call takes the N-aware kernels whenever one of its contigs holds an N (rounds 1-3): same results."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_N_BY_CONTIG"):
+        pytest.skip("already inside the child")
+    env = dict(os.environ, GAMDP_N_BY_CONTIG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "one_n_around or window_cases or random_cases or reverse_complement_and"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
 def test_band_too_wide_is_refused_loudly():
     c = ctx()
     sset = gam.SequenceSet(c, [b"ACGT" * 10, b"ACGT" * 10])
@@ -624,7 +721,7 @@ def test_four_tasks_per_wavefront_kernels_in_a_fresh_process():
     import os, subprocess, sys
     if os.environ.get("GAMDP_QUAD_MIN"):
         pytest.skip("already inside the four-task child")
-    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks or window_cases or paths_in_every_strip"
+    sel = "band150_stress or random_cases or medium_pairs or golden_large or golden_small or begin_a_at or row_cap or packed_top_blocks or window_cases or paths_in_every_strip or one_n_around"
     for extra in ({}, dict(GAMDP_NO_PAIR="1"), dict(GAMDP_DIAG_FORCE_N="1", GAMDP_LIB=DIAG_LIB), dict(GAMDP_DIAG_NO_DIRFREE="1", GAMDP_LIB=DIAG_LIB)):
         env = dict(os.environ, GAMDP_QUAD_MIN="1", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", sel],
