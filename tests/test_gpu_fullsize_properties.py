@@ -120,3 +120,40 @@ def test_throughput_kernels_agree_with_each_other_and_the_oracle_at_batch_size()
         assert tuple(keys[150][k]) == tuple(o.key()), k
     sset.close()
 
+
+
+def _mid_batch_digest():
+    """16 384 library-generated 3 kb pairs at band 150 through whatever kernel the launch planner picks: CRC of every result key."""
+    import zlib
+    from gam_ngs_amd import lib as L
+    c = ctx()
+    P, n = 16384, 3000
+    sset = gam.SequenceSet.synthetic(c, 9000, P, n)
+    tasks = (L.Task * P)()
+    for k in range(P):
+        t = tasks[k]
+        t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, 150
+        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, n - 1, 0, sset.lengths[2 * k + 1] - 1
+    out = (L.Result * P)()
+    assert c.lib.gamdp_align_batch(c.handle, sset.handle, sset.handle, tasks, P, out, None) == 0
+    keys = [tuple(out[k].key()) for k in range(P)]
+    sset.close()
+    return zlib.crc32(repr(keys).encode()), keys
+
+
+def test_the_launch_planner_s_kernel_choice_does_not_change_results():
+    """Round 4 moved the thresholds of the eight-task kernel (batches of 12 288+ N-free band-150 calls of 1 536+ rows): the same 16 384
+    pairs of 3 kb through the planner's choice (eight tasks per wavefront) and, in a child process with GAMDP_OCTO_MIN_ROWS out of
+    reach, through the one-task kernel must give the same results, and a sample must equal the oracle."""
+    import os, subprocess, sys
+    crc, keys = _mid_batch_digest()
+    for k in (0, 1, 4095, 8192, 16383, 7777):
+        m, s = api.synth_pair(9000 + k, 3000)
+        o, _ = O.oracle_align(m, s, 150, 0, 2999, 0, len(s) - 1, want_ops=False)
+        assert keys[k] == tuple(o.key()), k
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_fullsize_properties as T\nprint('CRC', T._mid_batch_digest()[0])\n") % (here, os.path.dirname(here))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GAMDP_OCTO_MIN_ROWS="100000000"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert ("CRC %d" % crc) in r.stdout, (crc, r.stdout[-300:])
