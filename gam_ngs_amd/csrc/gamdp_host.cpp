@@ -908,7 +908,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     // whole batch would sit in front of / behind the kernel (25 ms of a 120 ms step for 400 000 5 kb pairs).  They go
     // through in four pieces on two host threads with a context (stream, staging, arena) each: one piece's host work
     // runs while the other's kernel does.  Results do not depend on the split.
-    // (From 65 536 calls on when the calls are small -- by their windows under ~12 M cell updates each, 7 M at band 150 whose
+    // (From 65 536 calls on when the calls are small -- by their windows under ~8 M cell updates each, 4.5 M at band 150 whose
     // eight-task wavefronts hold eight direction images per scratch slot: 11 kb at band 512, 23 kb at band 150 -- since the
     // first piece is small (below): 200 000 x 5 kb at band 512 9 110 -> 9 780 GCUPS.  Batches of long calls stay whole whatever
     // their number: the two contexts share the scratch arena, and four short launches would lose more
@@ -923,7 +923,10 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
             const gamdp_task& t = tasks[i];
             est += (t.end_b >= t.begin_b ? (double)std::min<u64>(t.end_b - t.begin_b + 1, 500000) : 0.0) * (2.0 * t.band + 1.0);
         }
-        chunked = est / (double)std::max<size_t>(1, cnt) < (tasks[0].band == 150 ? 7e6 : 12e6);
+        // (re-measured with the walk phase's priority in place, which only launches of more than two rounds get: 100 000 x 20 kb at band 150
+        // 81 ms in pieces, 72 - 79 whole; 100 000 x 10 kb at band 512 92.5 in pieces, 88.4 whole; 200 000 x 5 kb at band 512 97 - 105 in pieces,
+        // 106 - 107 whole; 200 000 x 10 kb at band 150 a tie)
+        chunked = est / (double)std::max<size_t>(1, cnt) < (tasks[0].band == 150 ? 4.5e6 : 8e6);
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor
