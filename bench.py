@@ -472,8 +472,12 @@ def main():
         }
         if weak is not None:
             line["weak"] = weak
-        if m["bad_all"] and not os.environ.get("GAMDP_BENCH_IGNORE_FAILED"):   # (timing experiments with unusable results)
-            raise SystemExit("bench.py: %d pairs came back without an alignment" % int(m["bad_all"]))
+        if m["bad_all"]:
+            if not os.environ.get("GAMDP_BENCH_IGNORE_FAILED"):   # (timing experiments with unusable results)
+                raise SystemExit("bench.py: %d pairs came back without an alignment" % int(m["bad_all"]))
+            line["results_unusable"] = True
+            print("bench.py: WARNING: %d pairs came back without an alignment (GAMDP_BENCH_IGNORE_FAILED): NOT a valid measurement"
+                  % int(m["bad_all"]), file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             n_cpu = min(args.cpu_pairs or 32 * min(os.cpu_count() or 1, 16), m["P"])
             # the sample is spread over the whole list (the list order is also the order in which a launch pairs tasks

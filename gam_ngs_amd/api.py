@@ -52,6 +52,14 @@ class Context:
         self.lib.gamdp_ctx_kernel_time(self.handle, C.byref(ms), C.byref(n), int(reset))
         return ms.value, n.value
 
+    def launch_info(self):
+        """The launches of the last gamdp_align_batch call on this context, as dicts (gamdp_ctx_launch_info)."""
+        n = C.c_size_t()
+        self.lib.gamdp_ctx_launch_info(self.handle, None, 0, C.byref(n))
+        arr = (L.LaunchInfo * max(1, n.value))()
+        self.lib.gamdp_ctx_launch_info(self.handle, arr, n.value, C.byref(n))
+        return [arr[i].as_dict() for i in range(n.value)]
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.gamdp_ctx_destroy(self.handle)

@@ -81,7 +81,11 @@ struct LaunchParams {
     // prio_R = the block count of the launch's largest task (0 = off).  The host switches it on for the units that are in
     // flight when the queue runs dry: all of a launch of at most two rounds, the last n_slots of a longer one.
     u32 prio_R, prio_from;
+    // What the wavefronts did, counted on the device (LS_* below; lane 0 of a unit adds to it): the library's account of a launch
+    // (gamdp_ctx_launch_info).  nullptr = not counted (the chain kernels).
+    u32* stats;
 };
+enum : int { LS_UNITS = 0, LS_DIRFREE, LS_PACKED_TOP, LS_PACKED_TOP_MIXED, LS_STRIPS, LS_COUNT = 8 };
 // the two-task kernel walks its two tasks side by side (kernel_walk.inc) instead of one after the other: set by the host for
 // launches of at most two rounds, where the wavefronts of a SIMD walk at the same time and the scalar unit is the bottleneck
 constexpr u32 LP_WALK_SIDE_BY_SIDE = 1;
@@ -241,6 +245,8 @@ int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* 
 int chain_slots_per_workgroup();   // scratch slots a k_chain2 workgroup goes round (1 + its walker wavefronts)
 
 int kernel_cols(int kid);
+const char* kernel_name(int kid);      // the instantiation as rocprofv3 prints it, e.g. "k_align_o<19,15>"
+bool kernel_n_aware(int kid);
 bool kernel_dirfree(int kid);          // its fast blocks can run without directions (when the launch provides ckpt_off / bnd_off)
 int kernel_dir_block_words(int kid);  // words per block (16 row-times) of a task's direction image
 // launches on `stream`; returns hipError_t as int

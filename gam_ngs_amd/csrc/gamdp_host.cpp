@@ -12,9 +12,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -266,7 +263,8 @@ int Ctx::init(int dev)
         return GAMDP_ENODEV;
     }
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return GAMDP_ENODEV; }
-    if (hipMalloc(&d_cursor, 64 * sizeof(u32)) != hipSuccess) { set_error("hipMalloc failed"); return GAMDP_ENOMEM; }
+    cap_cursor = 64;
+    if (hipMalloc(&d_cursor, (size_t)cap_cursor * (1 + LS_COUNT) * sizeof(u32)) != hipSuccess) { set_error("hipMalloc failed"); return GAMDP_ENOMEM; }
     return 0;
 }
 
@@ -345,7 +343,7 @@ static int pick_kernel(int band, bool has_n)
     return K_GEN_C17;
 }
 
-// fn(lo, hi) over [0, n) on the process's host thread pool (gamdp_internal.h: HostPool); batches of a few thousand tasks are not worth a thread
+// fn(lo, hi) over [0, n) on the process's host thread pool (gamdp_hostpool.h: HostPool); batches of a few thousand tasks are not worth a thread
 template <class F>
 static void parallel_for(size_t n, F fn)
 {
@@ -546,7 +544,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // 6 144 tasks 19.3 against 24.1 ms, 16 384 tasks 32.1 against 41.4 ms (four-task kernel), 4 096 tasks 18.6 against 12.3)
             // (round 4, with the top blocks packed and the strips centred on the band's middle column: from ~1.5 k rows on -- 400 000 x 2 kb
             // 4 450 -> 5 500 GCUPS, x 3 kb 4 980 -> 6 200, x 1 kb 3 300 against 3 100 the other way; GAMDP_OCTO_MIN_ROWS overrides, A/B)
-            static const size_t octo_min_rows = [] { const char* e = std::getenv("GAMDP_OCTO_MIN_ROWS"); return e ? (size_t)std::atol(e) : (size_t)1536; }();
+            static const size_t octo_min_rows = [] { const char* e = std::getenv("GAMDP_OCTO_MIN_ROWS"); return e ? (size_t)std::min(std::max(std::atol(e), 0L), 500000L) : (size_t)1536; }();
             // ... and from 12 288 calls on, not only from a chip-full of eight-task wavefronts (32 768): 16 384 x 5 kb 6.0 -> 5.0 ms, 24 576 x 5 kb
             // 8.7 -> 7.3, 16 384 x 2.5 kb 3.8 - 4.9 -> 3.7 - 3.8; 8 192 x 5 kb: equal
             const size_t avg_rows = rows / g.size();
@@ -715,16 +713,18 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             }
             cap_scratch = need_scratch;
         }
-        if (launches.size() > 64) {
-            // cursors: one u32 per launch
+        if (launches.size() > cap_cursor) {
+            // cursors: one u32 per launch, and LS_COUNT statistics words per launch behind them
             free_dev(d_cursor);
-            d_cursor = nullptr;
-            HIPCHK(this, hipMalloc(&d_cursor, launches.size() * sizeof(u32)));
+            d_cursor = nullptr; cap_cursor = 0;
+            HIPCHK(this, hipMalloc(&d_cursor, launches.size() * (1 + LS_COUNT) * sizeof(u32)));
+            cap_cursor = (u32)launches.size();
         }
+        u32* const d_stats = d_cursor + cap_cursor;
         const double ms_plan = since(t_begin) - ms_prep;
         const auto t_gpu = std::chrono::steady_clock::now();
         HIPCHK(this, hipMemcpyAsync(d_tasks, h_tasks, n_host_tasks * sizeof(DevTask), hipMemcpyHostToDevice, stream));
-        HIPCHK(this, hipMemsetAsync(d_cursor, 0, std::max<size_t>(64, launches.size()) * sizeof(u32), stream));
+        HIPCHK(this, hipMemsetAsync(d_cursor, 0, (size_t)cap_cursor * (1 + LS_COUNT) * sizeof(u32), stream));
         while (events.size() < launches.size()) {
             hipEvent_t a, b;
             HIPCHK(this, hipEventCreate(&a));
@@ -738,7 +738,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.results = d_results; p.ops_buf = d_ops;
             p.scratch = d_scratch; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
             p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
-            static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::atol(e) : 2ull; }();
+            p.stats = d_stats + li * LS_COUNT;
+            static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::min(std::max(std::atol(e), 0L), 1000000L) : 2ull; }();
             p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
             static const bool no_packed_top = std::getenv("GAMDP_NO_PACKED_TOP") != nullptr;
             if (no_packed_top) p.flags |= LP_NO_PACKED_TOP;
@@ -768,6 +769,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         HIPCHK(this, hipMemcpyAsync(hres, d_results, n * sizeof(DevResult), hipMemcpyDeviceToHost, stream));
         std::vector<uint8_t> hops(ops_total);
         if (ops_total) HIPCHK(this, hipMemcpyAsync(hops.data(), d_ops, ops_total, hipMemcpyDeviceToHost, stream));
+        std::vector<u32> hstats(log_launches ? launches.size() * LS_COUNT : 0);
+        if (!hstats.empty()) HIPCHK(this, hipMemcpyAsync(hstats.data(), d_stats, hstats.size() * sizeof(u32), hipMemcpyDeviceToHost, stream));
         HIPCHK(this, hipStreamSynchronize(stream));
         const double ms_gpu = since(t_gpu);
         if (diag_timing) {
@@ -777,6 +780,28 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
+            if (log_launches) {   // gamdp_ctx_launch_info: the planner's choice and what the device counted
+                const Launch& L = launches[li];
+                gamdp_launch_info r;
+                std::memset(&r, 0, sizeof(r));
+                std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel_name(L.kid));
+                r.n_aware = kernel_n_aware(L.kid) ? 1u : 0u;
+                r.tasks_per_wavefront = (u32)kernel_tasks_per_wave(L.kid);
+                r.tasks = (u32)launch_items[li].size();
+                r.units = L.count / r.tasks_per_wavefront;
+                r.slots = L.n_slots;
+                r.band_max = (L.ypad - 2) / 2;   // (rounded up to the side buffers' stride; the exact band follows below)
+                u32 bm = 0;
+                for (u32 i : launch_items[li]) bm = std::max<u32>(bm, (u32)prep[i].dt.band);
+                r.band_max = bm;
+                const u32* st = hstats.data() + li * LS_COUNT;
+                r.units_dirfree = st[LS_DIRFREE]; r.units_packed_top = st[LS_PACKED_TOP]; r.units_packed_top_mixed = st[LS_PACKED_TOP_MIXED];
+                r.strips = st[LS_STRIPS];
+                r.piece = log_piece;
+                r.rounds = L.n_slots ? (double)r.units / (double)L.n_slots : 0.0;
+                r.kernel_ms = (double)ms;
+                launch_log.push_back(r);
+            }
             if (interval_sink && ref_event) {  // merge-block calls: where this launch sat on the call's time line
                 float t0 = 0;
                 if (hipEventElapsedTime(&t0, ref_event, events[li].first) == hipSuccess) interval_sink->push_back({t0, t0 + ms});
@@ -853,6 +878,15 @@ int gamdp_ctx_kernel_time(gamdp_ctx* ctx, double* total_ms, uint64_t* launches, 
     return 0;
 }
 
+int gamdp_ctx_launch_info(const gamdp_ctx* ctx, gamdp_launch_info* out, size_t cap, size_t* n)
+{
+    if (!ctx || (cap && !out)) return GAMDP_EINVAL;
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    if (n) *n = c->launch_log.size();
+    for (size_t i = 0; i < c->launch_log.size() && i < cap; i++) out[i] = c->launch_log[i];
+    return 0;
+}
+
 int gamdp_seqset_create(gamdp_ctx* ctx, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n, int is_ascii,
                         gamdp_seqset** out)
 {
@@ -890,6 +924,9 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     const SeqSet* sa = reinterpret_cast<const SeqSet*>(set_a);
     const SeqSet* sb = reinterpret_cast<const SeqSet*>(set_b);
+    c->launch_log.clear();
+    struct LogGuard { Ctx* c; ~LogGuard() { c->log_launches = false; for (Ctx* h : c->helpers) h->log_launches = false; } } log_guard{c};
+    c->log_launches = true; c->log_piece = 0;
     return guarded(c, [&]() -> int {
     if (c->arena_budget(true) == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
     auto run = [&](Ctx* cc, size_t first, size_t cnt) -> int {
@@ -919,14 +956,20 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     if (chunk_env < 0 && n >= 65536) {
         double est = 0;   // (a sample of the windows is enough: every 64th call)
         size_t cnt = 0;
+        size_t n150 = 0;
         for (size_t i = 0; i < n; i += 64, cnt++) {
             const gamdp_task& t = tasks[i];
-            est += (t.end_b >= t.begin_b ? (double)std::min<u64>(t.end_b - t.begin_b + 1, 500000) : 0.0) * (2.0 * t.band + 1.0);
+            // rows as the pre-checks will size them (banded_smith_waterman.cc:91-95): end_b clipped to the contig, no wrap of the + 1
+            const u64 blen = t.b_id < sb->lens.size() ? sb->lens[t.b_id] - std::min<u64>(t.b_off, sb->lens[t.b_id]) : 0;
+            const u64 eb = blen ? std::min<u64>(t.end_b, blen - 1) : 0;
+            const u64 rows = (blen && eb >= t.begin_b) ? std::min<u64>(eb - t.begin_b + 1, 500000) : 0;
+            est += (double)rows * (2.0 * t.band + 1.0);
+            n150 += t.band == 150;
         }
         // (re-measured with the walk phase's priority in place, which only launches of more than two rounds get: 100 000 x 20 kb at band 150
         // 81 ms in pieces, 72 - 79 whole; 100 000 x 10 kb at band 512 92.5 in pieces, 88.4 whole; 200 000 x 5 kb at band 512 97 - 105 in pieces,
         // 106 - 107 whole; 200 000 x 10 kb at band 150 a tie)
-        chunked = est / (double)std::max<size_t>(1, cnt) < (tasks[0].band == 150 ? 4.5e6 : 8e6);
+        chunked = est / (double)std::max<size_t>(1, cnt) < (2 * n150 >= cnt ? 4.5e6 : 8e6);   // (the band of most of the sampled calls)
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor
@@ -955,16 +998,18 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     cc[0]->arena_div = cc[1]->arena_div = 2;
     cc[0]->trim_scratch(); cc[1]->trim_scratch();
     cc[1]->kernel_ms = 0; cc[1]->kernel_launches = 0;
+    cc[1]->launch_log.clear(); cc[1]->log_launches = true;
     // Four pieces, the first one small: nothing runs on the GPU until the first piece is validated, sorted and staged, and
     // that costs ~5 ms per 100 000 tasks -- so the first piece is an eighth of the batch (GAMDP_CHUNK_FIRST_DIV), the other three
     // share the rest; the second thread prepares piece 1 meanwhile.
-    static const size_t first_div = [] { const char* e = std::getenv("GAMDP_CHUNK_FIRST_DIV"); const long v = e ? std::atol(e) : 8; return (size_t)std::max(4L, v); }();
+    static const size_t first_div = [] { const char* e = std::getenv("GAMDP_CHUNK_FIRST_DIV"); const long v = e ? std::atol(e) : 8; return (size_t)std::min(std::max(4L, v), 1024L); }();
     const size_t pieces = 4, n0 = n / first_div, per = (n - n0 + 2) / 3;
     size_t bound[5] = {0, n0, std::min(n, n0 + per), std::min(n, n0 + 2 * per), n};
     int rc[2] = {0, 0};
     auto worker = [&](int t) noexcept {
         for (size_t k = (size_t)t; k < pieces && rc[t] == 0; k += 2) {
             const size_t first = bound[k], cnt = bound[k + 1] - bound[k];
+            cc[t]->log_piece = (u32)k;
             if (cnt) rc[t] = guarded(cc[t], [&] { return run(cc[t], first, cnt); });
         }
     };
@@ -974,6 +1019,8 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         worker(0);
     }
     c->kernel_ms += cc[1]->kernel_ms; c->kernel_launches += cc[1]->kernel_launches;
+    c->launch_log.insert(c->launch_log.end(), cc[1]->launch_log.begin(), cc[1]->launch_log.end());
+    std::stable_sort(c->launch_log.begin(), c->launch_log.end(), [](const gamdp_launch_info& x, const gamdp_launch_info& y) { return x.piece < y.piece; });
     if (rc[1]) c->set_error(cc[1]->err);
     return rc[0] ? rc[0] : rc[1];
     });

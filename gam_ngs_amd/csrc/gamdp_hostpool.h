@@ -14,15 +14,21 @@ namespace gamdp {
 
 // The parallel loops of a batch call: fn(lo, hi) over [0, n) on up to 16 host threads.
 // The threads are the process's own and stay: starting and joining 15 threads cost a parallel loop 0.5 - 0.8 ms, four
-// loops per batch call.  One parallel loop at a time -- a second caller (another context's thread) runs its loop itself.
+// loops per batch call.  One parallel loop at a time: a second caller (the other thread of a batch that goes through in pieces, the
+// host thread of another device) waits its turn when its loop is large -- every loop then still runs on all threads, one after
+// the other -- and runs a small loop itself, on its own thread, instead of waiting.
 class HostPool {
 public:
     static HostPool& get() { static HostPool p; return p; }
     template <class F>
     void run(size_t n, F& fn)
     {
+        if (workers_.empty()) { fn((size_t)0, n); return; }
         std::unique_lock<std::mutex> one(use_, std::try_to_lock);
-        if (!one.owns_lock() || workers_.empty()) { fn((size_t)0, n); return; }
+        if (!one.owns_lock()) {
+            if (n < kWaitFrom) { fn((size_t)0, n); return; }
+            one.lock();
+        }
         const unsigned parts = (unsigned)workers_.size() + 1;
         auto body = [&](unsigned k) { fn(n * k / parts, n * (k + 1) / parts); };
         {
@@ -36,6 +42,7 @@ public:
         cv_done_.wait(g, [&] { return done_ == parts_; });
         job_ = nullptr;
     }
+    static constexpr size_t kWaitFrom = 32768;   // elements from which a caller that finds the pool busy waits for it
 private:
     HostPool()
     {

@@ -116,7 +116,12 @@ struct Ctx {
     DevTask* d_tasks = nullptr; u64 cap_tasks = 0;
     DevResult* d_results = nullptr; u64 cap_results = 0;
     uint8_t* d_ops = nullptr; u64 cap_ops = 0;
-    u32* d_cursor = nullptr;
+    u32* d_cursor = nullptr;         // [cap_cursor] work-queue heads, then [cap_cursor][LS_COUNT] device-side launch statistics
+    u32 cap_cursor = 0;
+    // gamdp_ctx_launch_info: what the last gamdp_align_batch call launched (Ctx::align appends while log_launches is set)
+    std::vector<gamdp_launch_info> launch_log;
+    bool log_launches = false;
+    u32 log_piece = 0;
     DevTask* h_tasks = nullptr;      // pinned staging
     DevResult* h_results = nullptr;  // pinned staging
     u64 cap_pinned = 0;

@@ -53,6 +53,17 @@ __shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise
 #include "kernel_strip.inc"
 #include "kernel_finish.inc"
 
+// the device's side of gamdp_ctx_launch_info: lane 0 of a unit counts what the unit did
+__device__ __forceinline__ void count_unit(const LaunchParams& p, const int lane, const bool dirfree, const bool packed_top, const bool mixed_top)
+{
+    if (p.stats != nullptr && lane == 0) {
+        atomicAdd(p.stats + LS_UNITS, 1u);
+        if (dirfree) atomicAdd(p.stats + LS_DIRFREE, 1u);
+        if (packed_top) atomicAdd(p.stats + LS_PACKED_TOP, 1u);
+        if (mixed_top) atomicAdd(p.stats + LS_PACKED_TOP_MIXED, 1u);
+    }
+}
+
 // block modes of one task (scalar) and its runs: b0 = first fast block, b1 = first block after that fast run
 struct Plan { int nblk, b0, b1, b2; int64_t iE0, iE1; int X, LE, begin_a, w; };  // b2 = first block after the end run that follows
 __device__ __forceinline__ int plan_mode(const Plan& pl, const int blk)
@@ -182,6 +193,7 @@ __device__ __forceinline__ void run_task(const DevTask& dt, const LaunchParams& 
     Tk t;
     t.cancel = nullptr;
     fill_task<C, CE, HASN>(dt, p, slot, lane, lrpt, t);
+    count_unit(p, lane, t.df_hi > t.df_lo, false, false);
     if (t.prio_R != 0) __builtin_amdgcn_s_setprio(0);   // end cell + walk: few vector instructions, whoever still fills goes first
     finish_task<C, CE, HASN>(&t, &dt, &p, lane);
 }
@@ -389,6 +401,7 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
         else top_from = top_to = 0;
     }
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
+    count_unit(p, lane, hi > lo, top_to > top_from, false);
     if (p.prio_R != 0 && qi >= p.prio_from) {
         ta.prio_R = tb.prio_R = (int)p.prio_R;
         ta.prio_nblk = tb.prio_nblk = max(pa.nblk, pb.nblk);
@@ -498,6 +511,7 @@ __device__ __forceinline__ void run_quad(const LaunchParams& p, const u32 qi, u3
         if (hi - lo >= 8 && e_min > lo) { t.df_lo = lo; t.df_hi = hi; }
     }
     const int df_lo = t.df_lo, df_hi = t.df_hi;  // wave-uniform by construction
+    count_unit(p, lane, df_hi > df_lo, false, false);
     for (int blk = 0; blk < nblk_max;) {
         if (df_hi > df_lo && blk == df_lo) {
             const int f_hi = min(df_hi, e_min);
@@ -582,6 +596,7 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
         }
     }
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
+    count_unit(p, lane, hi > lo, top_to > top_from, false);
     if (p.prio_R != 0 && qi >= p.prio_from) {
         ta.prio_R = tb.prio_R = (int)p.prio_R;
         ta.prio_nblk = tb.prio_nblk = max(nA, nB);
@@ -779,7 +794,7 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = (u64)uni64((int64_t)mbp->slot_words); p.dir_words = (u64)uni64((int64_t)mbp->dir_words); p.ypad = cp.ypad;
-    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.flags = 0; p.prio_R = 0; p.prio_from = 0; p.stats = nullptr;
     if constexpr (HASN) {
         if (uni((int)cp.mbs[mi].has_n) != 0) run_chain<true>(cp, p, mi, slot, lane);
         else run_chain<false>(cp, p, mi, slot, lane);
@@ -969,7 +984,7 @@ __global__ __launch_bounds__(64 * (1 + CH_NW), GAMDP_WAVES_PER_SIMD) void k_chai
     LaunchParams p;
     p.tasks = nullptr; p.n_tasks = 0; p.cursor = nullptr; p.results = cp.audit; p.ops_buf = nullptr;
     p.scratch = cp.scratch; p.slot_words = (u64)uni64((int64_t)mbp->slot_words); p.dir_words = (u64)uni64((int64_t)mbp->dir_words); p.ypad = cp.ypad;
-    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.flags = 0; p.prio_R = 0; p.prio_from = 0;
+    p.ckpt_off = (u64)uni64((int64_t)mbp->ckpt_off); p.bnd_off = (u64)uni64((int64_t)mbp->bnd_off); p.flags = 0; p.prio_R = 0; p.prio_from = 0; p.stats = nullptr;
     if (threadIdx.x == 0) {
         s_mail.filled = 0; s_mail.quit = 0; s_mail.total = 0; s_mail.claim = 0; s_mail.n_done = 0;
         for (int k = 0; k < CH_NS; ++k) { s_mail.early_of[k] = 0; s_mail.done_of[k] = 0; }
@@ -1017,6 +1032,33 @@ int kernel_cols(int kid)
     case K_GEN_C3: return 3;
     case K_GEN_C9: return 9;
     default: return 0;
+    }
+}
+
+const char* kernel_name(int kid)
+{
+    switch (kid) {
+    case K_C17_CE4:    return "k_align<17,4,false>";
+    case K_C17_CE4_N:  return "k_align<17,4,true>";
+    case K_C5_CE0:     return "k_align<5,0,false>";
+    case K_C5_CE0_N:   return "k_align<5,0,true>";
+    case K_P17_CE4:    return "k_align_p<17,4>";
+    case K_O19_CE15:   return "k_align_o<19,15>";
+    case K_Q19_CE15:   return "k_align_q<19,15,false>";
+    case K_Q19_CE15_N: return "k_align_q<19,15,true>";
+    case K_GEN_C2:     return "k_align<2,-1,true>";
+    case K_GEN_C3:     return "k_align<3,-1,true>";
+    case K_GEN_C5:     return "k_align<5,-1,true>";
+    case K_GEN_C9:     return "k_align<9,-1,true>";
+    case K_GEN_C17:    return "k_align<17,-1,true>";
+    default:           return "?";
+    }
+}
+bool kernel_n_aware(int kid)
+{
+    switch (kid) {
+    case K_C17_CE4: case K_C5_CE0: case K_P17_CE4: case K_O19_CE15: case K_Q19_CE15: return false;
+    default: return true;
     }
 }
 

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # every function include/gamdp.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "gamdp_ctx_create", "gamdp_ctx_destroy", "gamdp_ctx_set_arena_bytes", "gamdp_last_error", "gamdp_ctx_stream",
-    "gamdp_ctx_kernel_time", "gamdp_seqset_create", "gamdp_seqset_destroy", "gamdp_seqset_size",
+    "gamdp_ctx_kernel_time", "gamdp_ctx_launch_info", "gamdp_seqset_create", "gamdp_seqset_destroy", "gamdp_seqset_size",
     "gamdp_seqset_length", "gamdp_align_batch", "gamdp_align_merge_blocks", "gamdp_find_hits", "gamdp_encode",
     "gamdp_decode", "gamdp_revcomp", "gamdp_synth_pair", "gamdp_seqset_create_synth", "gamdp_seqset_create_synth_strided",
     "gamdp_fasta_open", "gamdp_fasta_close", "gamdp_fasta_count", "gamdp_fasta_name", "gamdp_fasta_codes",
@@ -80,6 +80,19 @@ class L1Stats(C.Structure):
                 ("host_feed_ms", C.c_double)]
 
 
+class LaunchInfo(C.Structure):
+    """gamdp_launch_info: one kernel launch of the last gamdp_align_batch call, as the library accounts for it."""
+    _fields_ = [("kernel", C.c_char * 40), ("n_aware", C.c_uint32), ("tasks_per_wavefront", C.c_uint32), ("tasks", C.c_uint32),
+                ("units", C.c_uint32), ("slots", C.c_uint32), ("band_max", C.c_uint32), ("units_dirfree", C.c_uint32),
+                ("units_packed_top", C.c_uint32), ("units_packed_top_mixed", C.c_uint32), ("strips", C.c_uint32),
+                ("piece", C.c_uint32), ("pad_", C.c_uint32), ("rounds", C.c_double), ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+        d["kernel"] = d["kernel"].decode()
+        return d
+
+
 class MBlock(C.Structure):
     _fields_ = [("m_id", C.c_int32), ("m_start", C.c_int32), ("m_end", C.c_int32), ("s_id", C.c_int32),
                 ("s_start", C.c_int32), ("s_end", C.c_int32), ("align_rev", C.c_uint8), ("align_ok", C.c_uint8),
@@ -139,6 +152,7 @@ def load_library():
     lib.gamdp_ctx_stream.argtypes = [vp]
     lib.gamdp_ctx_stream.restype = vp
     lib.gamdp_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.c_int]
+    lib.gamdp_ctx_launch_info.argtypes = [vp, C.POINTER(LaunchInfo), C.c_size_t, C.POINTER(C.c_size_t)]
     lib.gamdp_seqset_create.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(u64), u32, C.c_int, C.POINTER(vp)]
     lib.gamdp_seqset_destroy.argtypes = [vp]
     lib.gamdp_seqset_destroy.restype = None

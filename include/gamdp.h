@@ -139,6 +139,29 @@ const char* gamdp_last_error(const gamdp_ctx* ctx);
 void* gamdp_ctx_stream(gamdp_ctx* ctx);
 /* HIP-event timing of the DP kernel launches since the last reset: total ms and launch count */
 int gamdp_ctx_kernel_time(gamdp_ctx* ctx, double* total_ms, uint64_t* launches, int reset);
+/* What the last gamdp_align_batch call on this context launched, in launch order (the pieces of a batch that went through in
+ * pieces included): the library's own account of its launch planner's choices (which kernel instantiation a group of calls
+ * took, how many wavefront slots, how many rounds) and of what the wavefronts then did on the device (counted there).
+ * No reference counterpart: BandedSmithWaterman::find_alignment (banded_smith_waterman.cc:69) is one code path. */
+typedef struct gamdp_launch_info {
+    char kernel[40];                 /* the instantiation, e.g. "k_align_o<19,15>" */
+    uint32_t n_aware;                /* 1: the instantiation handles N (v_dot8 cells) */
+    uint32_t tasks_per_wavefront;    /* 1, 2, 4 or 8 */
+    uint32_t tasks;                  /* calls in the launch (the copies that fill up its last wavefront not counted) */
+    uint32_t units;                  /* wavefront units handed out: tasks / pairs / quads / octets */
+    uint32_t slots;                  /* resident wavefronts = scratch slots */
+    uint32_t band_max;               /* widest band among the calls */
+    uint32_t units_dirfree;          /* units that ran a direction-free range (counted on the device) */
+    uint32_t units_packed_top;       /* ... whose blocks with pos <= 0 cells ran packed (device) */
+    uint32_t units_packed_top_mixed; /* ... of those, through the per-task form: calls that differ in begin_a / force_start calls (device) */
+    uint32_t strips;                 /* strip re-creations (materialise calls) of the launch's walks (device) */
+    uint32_t piece;                  /* piece of a batch that went through in pieces (0 = the whole batch / its first piece) */
+    uint32_t pad_;
+    double rounds;                   /* units / slots */
+    double kernel_ms;                /* HIP events on the library's stream */
+} gamdp_launch_info;
+/* copies up to `cap` records to out (may be NULL when cap == 0); *n = how many launches the call made */
+int gamdp_ctx_launch_info(const gamdp_ctx* ctx, gamdp_launch_info* out, size_t cap, size_t* n);
 
 /* ---- sequences ---------------------------------------------------------------------------- */
 /* seqs[i] points to lens[i] bytes: ASCII bases when is_ascii!=0 (normalised like Nucleotide(char)),
