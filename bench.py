@@ -27,6 +27,9 @@ The printed JSON line also carries
                   two-assembly workload: merge blocks/s, GCUPS, share of the call spent in GPU kernels, rounds;
   band150         the headline's own pairs once more at band 150, gam-merge's live band (N = 1, default workload only):
                   GCUPS, kernel, roofline fraction, and a sample verified against the CPU path like the headline's.
+  mixed150        a batch shaped like the live driver's calls (100 000 band-150 calls: random windows, force-flag tails, mixed lengths,
+                  a few contigs with N) through the planner's own choice: GCUPS, the kernel mix the library reports, a verified sample.
+  launch_info     what the library says it launched in the last step (gamdp_ctx_launch_info): roofline.kernel comes from there.
   strong8_proxy   (and strong4_proxy) the share ONE GPU gets of the fixed list in a strong-scaling run at N = 8 (4) --
                   pairs 0, 8, 16, ... -- timed on this GPU: GCUPS and projected_Ngpu_factor = N * gcups / value.  A
                   one-GPU stand-in for the scaling curve the driver measures when it has an 8-GPU node; a sample is
@@ -115,23 +118,17 @@ def cpu_baseline(length, band, pair_ids):
     return rec, keys
 
 
-def kernel_name(band, n_tasks=0, length=50000):
-    """The kernel instantiation the library picks for N-free contigs of this band and batch size (gamdp_host.cpp)."""
-    from gam_ngs_amd import lib as L
-    forced_n = bool(os.environ.get("GAMDP_DIAG_FORCE_N")) and L.load_library().gamdp_build_info() & 1
-    n = "true" if forced_n else "false"
-    if band == 512:
-        if n == "false" and n_tasks >= 2 and not os.environ.get("GAMDP_NO_PAIR"):
-            return "k_align_p<17,4>"      # two tasks per wavefront, fast blocks in packed f16
-        return "k_align<17,4,%s>" % n
-    if band == 150:
-        # >= 32 768 N-free tasks of >= 4 k rows: eight per wavefront, packed f16; >= 5 120 tasks of >= 8 k rows: four
-        if n == "false" and ((n_tasks >= 32768 and length >= 4096) or (n_tasks >= 6144 and length >= 8192)) and not os.environ.get("GAMDP_NO_PAIR"):
-            return "k_align_o<19,15>"
-        return ("k_align_q<19,15,%s>" if (n_tasks >= 5120 and length >= 8192) else "k_align<5,0,%s>") % n
-    y = 2 * band + 1
-    c = next(c for c in (2, 3, 5, 9, 17) if y <= c * 64)
-    return "k_align<%d,-1,true>" % c
+def launch_summary(ctx):
+    """What the library says the last batch call launched (gamdp_ctx_launch_info): (dominant kernel, records for the line).
+    The dominant kernel is the instantiation that took most of the call's kernel time."""
+    info = ctx.launch_info()
+    by_kernel = {}
+    for r in info:
+        by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0.0) + r["kernel_ms"]
+    dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
+    keep = ("kernel", "tasks", "units", "slots", "rounds", "band_max", "units_dirfree", "units_top_wanted", "units_packed_top",
+            "units_packed_top_mixed", "strips", "piece", "kernel_ms")
+    return dominant, [{k: (round(r[k], 3) if isinstance(r[k], float) else r[k]) for k in keep} for r in info]
 
 
 def measured_traffic(P_launch, length, band, launches_ok, kernel):
@@ -270,13 +267,14 @@ def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
         step()
     dt = (time.perf_counter() - t0) / steps
     kernel_ms, launches = ctx.kernel_time()
+    dominant, linfo = launch_summary(ctx)   # (of the last step: every step launches the same)
     cells = sum(out[k].cells for k in range(P))
     bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
     if bad:
         raise SystemExit("bench.py: %d pairs came back without an alignment at band 150" % bad)
     per_launch_s = kernel_ms / 1e3 / max(1, launches)
     rec = {"workload": "the same %d pairs at band 150" % P, "gcups": cells / dt / 1e9, "steps": steps, "ms_per_step": dt * 1e3,
-           "kernel": kernel_name(band, P, length), "kernel_ms_per_launch": per_launch_s * 1e3, "launches": int(launches),
+           "kernel": dominant, "launch_info": linfo, "kernel_ms_per_launch": per_launch_s * 1e3, "launches": int(launches),
            "roofline_frac": (cells * steps / max(1, launches)) * B_ALG / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s > 0 else 0.0}
     # counters of this workload, replayed from its committed profile set like the headline's (null when there is none)
     tb, tsrc, tcommit, thash = measured_traffic(P, length, band, launches == steps, rec["kernel"])
@@ -298,6 +296,74 @@ def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
         rec["verified_sample"] = "every %d-th pair of the list" % max(1, (P - 1) // max(1, len(pos) - 1))
     for k in range(P):
         tasks[k].band = 512
+    return rec
+
+
+def mixed150_record(ctx, n_pairs=12500, calls_per_pair=8, steps=2, warmup=1, verify=256, seed=20261004):
+    """A batch shaped like the live driver's calls (tests/_mixed.py: >= 100 000 band-150 calls on contigs of log-normal length 0.3 - 20 kb,
+    random windows on both contigs, a tenth of the calls force_start / force_end tails, ~1 % of the contigs with runs of N), through
+    the launch planner's own choice: GCUPS, the kernel mix as the library reports it, `verify` calls spread over the list compared
+    with the CPU path (the reference's own find_alignment where its build exists, else the oracle)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _mixed
+    import _oracle as O
+    import gam_ngs_amd as gam
+    from gam_ngs_amd import api, lib as L
+    seqs, calls = _mixed.mixed_batch(seed, n_pairs, calls_per_pair)
+    n = len(calls)
+    sset = gam.SequenceSet(ctx, seqs, ascii=False)
+    tasks = (L.Task * n)()
+    _mixed.fill_tasks(tasks, calls)
+    out = (L.Result * n)()
+
+    def step():
+        rc = ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, n, out, None)
+        if rc != 0:
+            raise SystemExit("gamdp_align_batch (mixed150) failed: %d %s" % (rc, ctx.lib.gamdp_last_error(ctx.handle)))
+
+    for _ in range(warmup):
+        step()
+    ctx.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    kernel_ms, launches = ctx.kernel_time()
+    dominant, linfo = launch_summary(ctx)
+    cells = sum(out[k].cells for k in range(n))
+    rows = [c["end_b"] - c["begin_b"] + 1 for c in calls]
+    octo = [r for r in linfo if r["kernel"].startswith("k_align_o")]
+    units = sum(r["units"] for r in octo)
+    rec = {"workload": "%d band-150 calls on %d contig pairs of log-normal length 0.3 - 20 kb: chain calls with random windows, "
+                       "%d force_start and %d force_end tail calls, %d calls that start inside the band's left triangle (tests/_mixed.py, seed %d)"
+                       % (n, n_pairs, sum(c["fs"] for c in calls), sum(c["fe"] for c in calls), sum(1 for c in calls if c["begin_a"] < 135), seed),
+           "calls": n, "mean_rows": sum(rows) / float(n), "gcups": cells / dt / 1e9, "steps": steps, "ms_per_step": dt * 1e3,
+           "kernel_ms_per_step": kernel_ms / steps, "launches_per_step": launches / float(steps), "kernel": dominant, "launch_info": linfo,
+           # of the eight-task wavefronts whose calls hold blocks with pos <= 0 cells behind the ramp, how many ran them packed
+           "packed_top_share": (sum(r["units_packed_top"] for r in octo) / float(max(1, sum(r["units_top_wanted"] for r in octo)))) if units else None,
+           "packed_top_units": sum(r["units_packed_top"] for r in octo), "octo_units": units,
+           "statuses": {str(st): sum(1 for k in range(n) if out[k].status == st) for st in sorted({out[k].status for k in range(n)})}}
+    if verify:
+        pos = strided_sample(n, verify)
+        ref = O.ref()
+        diff = []
+        for k in pos:
+            c = calls[k]
+            a, b = seqs[c["a_id"]][c["a_off"]:], seqs[c["b_id"]]
+            if ref is not None:
+                r, _ = O.ref_align(api.decode(a).encode(), api.decode(b).encode(), c["band"], c["begin_a"], c["end_a"], c["begin_b"], c["end_b"], c["fs"], c["fe"])
+                want = O.ref_key(r)
+            else:
+                r, _ = O.oracle_align(a, b, c["band"], c["begin_a"], c["end_a"], c["begin_b"], c["end_b"], c["fs"], c["fe"], want_ops=False)
+                want = r.key()
+            if tuple(out[k].key()) != tuple(want):
+                diff.append((k, out[k].key(), want))
+        if diff:
+            raise SystemExit("bench.py: mixed150: call %d differs from the CPU %s: %r vs %r (%d of %d differ)"
+                             % (diff[0][0], "reference" if ref is not None else "port", diff[0][1], diff[0][2], len(diff), len(pos)))
+        rec["verified_calls"] = len(pos)
+        rec["verified_against"] = "reference" if ref is not None else "port"
+    sset.close()
     return rec
 
 
@@ -331,6 +397,7 @@ def main():
     ap.add_argument("--l1-genome", type=int, default=2_900_000, help="genome size of the L1 workload (S. aureus: 2.9 Mb)")
     ap.add_argument("--no-band150", action="store_true", help="skip the band-150 record of the same pairs")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong8_proxy / strong4_proxy records")
+    ap.add_argument("--no-mixed150", action="store_true", help="skip the mixed150 record (a driver-shaped batch of 100 000 band-150 calls)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -409,12 +476,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         kernel_ms, launches = ctx.kernel_time()
+        dominant, linfo = launch_summary(ctx)
         cells_rank = sum(out[k].cells for k in range(P))
         bad = sum(1 for k in range(P) if out[k].status != L.ST_OK)
         dt_max, cells_all, bad_all = reduce_step_stats(dt, float(cells_rank), float(bad), device="cpu" if share_gpu else "cuda")
         m = dict(P=P, first=first, stride=stride, dt_max=dt_max, cells_all=cells_all, bad_all=bad_all, cells_rank=cells_rank,
                  kernel_ms=kernel_ms, launches=launches, t_setup=t_setup, gcups=cells_all * steps / dt_max / 1e9,
-                 keys=None)
+                 keys=None, kernel=dominant, launch_info=linfo)
         if rank == 0 and mode == args.scaling:
             m["gpu_keys"] = lambda n: [out[k].key() for k in range(n)]
             m["_keep"] = (sset, tasks, out)
@@ -435,7 +503,7 @@ def main():
         avg_launch_s = (m["kernel_ms"] / 1e3) / max(1, launches)
         cells_per_launch = m["cells_rank"] * steps / max(1, launches)
         achieved = cells_per_launch * B_ALG / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        kname = kernel_name(args.band, m["P"], length)
+        kname = m["kernel"] or "?"   # the library's own account of what it launched (gamdp_ctx_launch_info), not a mirror of its planner
         traffic_bytes, traffic_src, traffic_commit, traffic_hash = measured_traffic(m["P"], length, band, launches == steps, kname)
         line = {
             "metric": "GCUPS", "value": m["gcups"], "unit": "GCUPS", "n_gpus": world, "steps": steps,
@@ -470,6 +538,7 @@ def main():
                          "launches": int(launches), "algorithmic_bytes_per_cell": B_ALG,
                          "valu": valu_record(m["P"], length, band, kname, m["gcups"]) if world == 1 else None},
         }
+        line["launch_info"] = m["launch_info"]
         if weak is not None:
             line["weak"] = weak
         if m["bad_all"]:
@@ -505,6 +574,8 @@ def main():
             for ng in (8, 4):
                 line["strong%d_proxy" % ng] = strong_proxy_record(ctx, ng, args.pairs, length, band, m["gcups"],
                                                                   verify=0 if args.no_cpu_baseline else 128)
+        if not args.no_mixed150 and world == 1 and band == 512:
+            line["mixed150"] = mixed150_record(ctx, verify=0 if args.no_cpu_baseline else 256)
         if not args.no_l1 and world == 1:
             import bench_l1
             line["l1"] = bench_l1.run(ctx, genome=args.l1_genome, cpu=not args.no_cpu_baseline)

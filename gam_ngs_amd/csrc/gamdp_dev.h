@@ -44,7 +44,8 @@ enum : u32 { TF_FORCE_START = 1, TF_FORCE_END = 2, TF_WANT_OPS = 4,
              TF_DIAG_SKIP_TRACEBACK = 8 /* timing diagnostics only (GAMDP_DIAG_SKIP_TRACEBACK=1): results invalid */,
              TF_NO_DIRFREE = 16 /* GAMDP_DIAG_NO_DIRFREE=1: keep directions in every block (A/B measurements) */,
              TF_DIAG_COUNT_MAT = 32 /* GAMDP_DIAG_COUNT_MAT=1: n_match := number of materialise() calls (results invalid) */,
-             TF_PADDING = 64 /* a copy of a companion that fills a wavefront of the multi-task kernels: filled along, no end cell, no walk, no result */ };
+             TF_PADDING = 64 /* a copy of a companion that fills a wavefront of the multi-task kernels: filled along, no end cell, no walk, no result */,
+             TF_CALL_N = 128 /* chain kernels only: the bases this call touches may hold an N (chain_filler tells the walker which cell it filled with) */ };
 
 // the diagnostics flags only exist in the -DGAMDP_DIAG build: the product kernels mask them off at compile time, so a
 // stray flag (or environment variable) can neither skip the traceback nor overwrite result fields with counters
@@ -85,7 +86,7 @@ struct LaunchParams {
     // (gamdp_ctx_launch_info).  nullptr = not counted (the chain kernels).
     u32* stats;
 };
-enum : int { LS_UNITS = 0, LS_DIRFREE, LS_PACKED_TOP, LS_PACKED_TOP_MIXED, LS_STRIPS, LS_COUNT = 8 };
+enum : int { LS_UNITS = 0, LS_DIRFREE, LS_PACKED_TOP, LS_PACKED_TOP_MIXED, LS_STRIPS, LS_TOP_WANTED, LS_COUNT = 8 };
 // the two-task kernel walks its two tasks side by side (kernel_walk.inc) instead of one after the other: set by the host for
 // launches of at most two rounds, where the wavefronts of a SIMD walk at the same time and the scalar unit is the bottleneck
 constexpr u32 LP_WALK_SIDE_BY_SIDE = 1;
@@ -95,6 +96,9 @@ constexpr u32 LP_NO_PACKED_TOP = 2;
 // the strips of the direction-free ranges begin at multiples of the strip width, as before round 4 (Tk::sshift = 0): GAMDP_NO_STRIP_SHIFT=1
 // (A/B, and a second way through the tests)
 constexpr u32 LP_NO_STRIP_SHIFT = 4;
+// the packed top blocks only for wavefronts whose calls share begin_a and hold no force_start call, as in round 4 (the others keep the
+// int32 code): GAMDP_NO_PACKED_TOP_MIXED=1 (A/B, and a second way through the tests)
+constexpr u32 LP_NO_PACKED_TOP_MIXED = 16;
 // Issue priority of a wavefront of the two- / eight-task kernels while it is in its end-cell / strip / walk phase: bits 8-9.  That phase
 // is latency (the walk: a memory round trip per diagonal run) and short dependent chains (a strip's tagged cells); at the level of the
 // fills beside it, it waits for issue slots on top of its own latencies and holds its slot -- and the three fills' only partner that
@@ -185,6 +189,26 @@ GAMDP_HD inline int preflight_hd(u64 alen, u64 blen, u64 band, u64 begin_a, u64 
     return S_OK;
 }
 
+// May bases [lo, hi] of a view of a sequence (reverse complement or not, chopped by `off` bases) hold an N?  pre[k] = number of N among
+// bases [0, 256 k) of the sequence in forward orientation (nullptr: none at all).  Positions outside the sequence do not count; the
+// answer is by blocks of 256 bases: "yes" a little more often than the truth, never less.  Shared by the host (SeqSet::window_has_n)
+// and the chain kernels, which pick the cell of every call by the window it touches.
+GAMDP_HD inline bool npre_window_has_n(const u32* pre, int64_t len, bool rc, u64 off, int64_t lo, int64_t hi)
+{
+    if (pre == nullptr) return false;
+    const int64_t o_lo = (int64_t)off + (lo > 0 ? lo : 0), o_hi = ((int64_t)off + hi < len - 1) ? (int64_t)off + hi : len - 1;
+    if (o_lo > o_hi) return false;
+    const int64_t f_lo = rc ? len - 1 - o_hi : o_lo, f_hi = rc ? len - 1 - o_lo : o_hi;
+    return pre[(f_hi / 256) + 1] != pre[f_lo / 256];
+}
+// the bases a call touches (banded_smith_waterman.cc:135-171: pos = begin_a - band + x + y), `margin` more on either side
+GAMDP_HD inline bool call_touches_n(const u32* pre_a, int64_t alen, bool a_rc, u64 a_off, const u32* pre_b, int64_t blen, bool b_rc, u64 b_off,
+                                    int64_t band, int64_t begin_a, int64_t begin_b, int64_t X, int64_t margin)
+{
+    return npre_window_has_n(pre_a, alen, a_rc, a_off, begin_a - band - margin, begin_a + X - 1 + band + margin) ||
+           npre_window_has_n(pre_b, blen, b_rc, b_off, begin_b - margin, begin_b + X - 1 + margin);
+}
+
 // ---- the main chain of a merge block on the device (k_chain, gamdp_kernel.hip) -----------------------------------------
 // One wavefront takes a merge block through alignBlocks' serial chain (PctgBuilder.cc:1617-1708: block k starts where block
 // k-1's last match ended, plus the gap between the blocks) and the orientation retry of findBestAlignment (:1420-1509)
@@ -203,7 +227,10 @@ struct DevMB {
     u32 audit_first;               // its first record in the audit list (room for 2 * n_blocks)
     u32 rows;                      // sum of its slave frames: the rows one pass of the chain fills
     u32 try_rev;                   // orientation of the first attempt
-    u32 has_n;                     // one of its two contigs holds an N: the chain runs the N-aware cells (12% slower)
+    u32 has_n;                     // one of its two contigs holds an N: its calls MAY need the N-aware cells (12 % more instructions per row)
+    // ... and which of them do is decided call by call, by the window the call touches (round 5: N by window for the chains too):
+    // the N counts per 256 bases of the two contigs, forward orientation (SeqSet::npre on the device; nullptr: no N in that contig)
+    const u32 *npre_a, *npre_b;
     // its scratch: slots sized for ITS longest call (x_size <= its longest slave frame), not the launch's
     u32 max_x;                     // the rows a slot has room for: a call that needs more ends the chain with state 3 (the host's round loop takes the merge block)
     u64 slot_off[2];               // word offset in ChainParams::scratch of the first slot of its workgroup / of its twin's (within the piece of the launch it is in)
@@ -215,7 +242,7 @@ struct ChainOut { u32 n_dp; u32 state; u32 t_begin, t_end; u32 hw, hw_twin; u32 
 //   // chain's scratch slots (nothing of the chain is used: the host takes the merge block through its round loop); bit 8: rev
 // What a call of a chain was run on, next to its result record (same index): the window the device derived (PctgBuilder.cc:1652-1677),
 // the orientation, the rows and the status of the pre-checks.  The host's replay derives the same call by itself and compares.
-struct ChainWin { u64 begin_a, end_a, begin_b, end_b; u32 X; u32 info; };   // info: bit 0 = the slave reverse-complemented, bits 8.. = status of the pre-checks (0 = the DP ran)
+struct ChainWin { u64 begin_a, end_a, begin_b, end_b; u32 X; u32 info; };   // info: bit 0 = the slave reverse-complemented, bit 1 = the call ran the N-aware cells, bits 8.. = status of the pre-checks (0 = the DP ran)
 // A long chain gets a twin: a second workgroup that runs the OTHER orientation (findBestAlignment's second attempt, :1463-1509)
 // at the same time instead of after the first has failed -- the merge blocks that need it (a first guess that was wrong, a merge
 // block that fails) are the ones a call waits for.  The two never wait for each other: each leaves its verdict here, and the one
@@ -239,6 +266,8 @@ struct ChainParams {
     DevResult* host_audit; ChainOut* host_out; u32* host_done; u32 epoch;
     ChainWin* host_win;
     u32 skew_call;                 // diagnostics build only (GAMDP_DIAG_CHAIN_SKEW=k): the device starts call k of every first attempt one base late on the slave; ~0u = off
+    u32 n_margin;                  // bases added on either side of a call's window when it is tested for N (64; the diagnostics build can shrink it: GAMDP_DIAG_N_WINDOW_SHRINK, the replay must notice)
+    u32 n_by_contig;               // 1: every call of a chain whose contigs hold N runs the N-aware cells (GAMDP_N_BY_CONTIG=1, GAMDP_DIAG_FORCE_N)
     u32 two_waves;                 // k_chain2: a workgroup of one filling and several walking wavefronts with chain_slots_per_workgroup() scratch slots of slot_words each
 };
 int launch_chain(const ChainParams& p, bool has_n, unsigned n_workgroups, void* stream);   // returns hipError_t as int

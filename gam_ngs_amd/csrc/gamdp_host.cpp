@@ -124,6 +124,18 @@ int SeqSet::upload(Ctx* ctx_, const uint8_t* const* seqs, const uint64_t* lens, 
     HIPCHK(ctx, hipMemcpyAsync(dn, hn.data(), hn.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (u32 i = 0; i < n; i++) fwd[i] = DevSeq{d2 + at[i] / 16, dn + at[i] / 32};
+    // the N counts per 256 bases, for the chain kernels' choice of cell call by call
+    dev_npre.assign(n, nullptr);
+    {
+        std::vector<u32> all;
+        std::vector<size_t> first(n, 0);
+        for (u32 i = 0; i < n; i++) { first[i] = all.size(); all.insert(all.end(), npre[i].begin(), npre[i].end()); }
+        if (!all.empty()) {
+            HIPCHK(ctx, hipMalloc(&d_npre, all.size() * sizeof(u32)));
+            HIPCHK(ctx, hipMemcpy(d_npre, all.data(), all.size() * sizeof(u32), hipMemcpyHostToDevice));
+            for (u32 i = 0; i < n; i++) if (!npre[i].empty()) dev_npre[i] = d_npre + first[i];
+        }
+    }
     return 0;
 }
 
@@ -170,6 +182,7 @@ int SeqSet::upload_synth(Ctx* ctx_, uint64_t first_pair, uint64_t stride_pairs, 
     fwd.resize(n);
     rc.assign(n, DevSeq{nullptr, nullptr});
     has_n.assign(n, 0);
+    dev_npre.assign(n, nullptr);
     const u64 stride = padded_bases(len + len / 8 + 64);  // fixed slot per sequence (slave length varies)
     const u64 total = stride * n;
     std::vector<u32> h2(total / 16 + 4, 0), hn(total / 32 + 4, 0);
@@ -240,6 +253,7 @@ SeqSet::~SeqSet()
 {
     if (d2) (void)hipFree(d2);
     if (dn) (void)hipFree(dn);
+    if (d_npre) (void)hipFree(d_npre);
     for (u32* p : rc_allocs) (void)hipFree(p);
 }
 
@@ -743,6 +757,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             p.flags = (L.kid == K_P17_CE4 && (u64)L.count / 2 <= side_rounds * L.n_slots) ? LP_WALK_SIDE_BY_SIDE : 0u;
             static const bool no_packed_top = std::getenv("GAMDP_NO_PACKED_TOP") != nullptr;
             if (no_packed_top) p.flags |= LP_NO_PACKED_TOP;
+            static const bool no_packed_top_mixed = std::getenv("GAMDP_NO_PACKED_TOP_MIXED") != nullptr;
+            if (no_packed_top_mixed) p.flags |= LP_NO_PACKED_TOP_MIXED;
             static const bool no_strip_shift = std::getenv("GAMDP_NO_STRIP_SHIFT") != nullptr;
             if (no_strip_shift) p.flags |= LP_NO_STRIP_SHIFT;
             {   // the end-cell / strip / walk phase of the two- and eight-task kernels issues one level above a steady-state fill in
@@ -796,7 +812,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 r.band_max = bm;
                 const u32* st = hstats.data() + li * LS_COUNT;
                 r.units_dirfree = st[LS_DIRFREE]; r.units_packed_top = st[LS_PACKED_TOP]; r.units_packed_top_mixed = st[LS_PACKED_TOP_MIXED];
-                r.strips = st[LS_STRIPS];
+                r.strips = st[LS_STRIPS]; r.units_top_wanted = st[LS_TOP_WANTED];
                 r.piece = log_piece;
                 r.rounds = L.n_slots ? (double)r.units / (double)L.n_slots : 0.0;
                 r.kernel_ms = (double)ms;
@@ -969,7 +985,13 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         // (re-measured with the walk phase's priority in place, which only launches of more than two rounds get: 100 000 x 20 kb at band 150
         // 81 ms in pieces, 72 - 79 whole; 100 000 x 10 kb at band 512 92.5 in pieces, 88.4 whole; 200 000 x 5 kb at band 512 97 - 105 in pieces,
         // 106 - 107 whole; 200 000 x 10 kb at band 150 a tie)
-        chunked = est / (double)std::max<size_t>(1, cnt) < (2 * n150 >= cnt ? 4.5e6 : 8e6);   // (the band of most of the sampled calls)
+        const bool b150 = 2 * n150 >= cnt;   // (the band of most of the sampled calls)
+        chunked = est / (double)std::max<size_t>(1, cnt) < (b150 ? 4.5e6 : 8e6);
+        // ... and only if a piece still keeps the chip busy for a few rounds: a piece of a round or less lasts as long as its longest
+        // call, four times over (round 5, the driver-shaped batch of 100 000 band-150 calls of 0.2 - 10 k rows: 29.5 ms in four pieces of
+        // 3 600 wavefronts each -- one round, 8 - 11 ms per piece whatever its work -- against one LPT-balanced launch of three rounds)
+        const double units_per_piece = (double)n * (7.0 / 24.0) / (b150 ? 8.0 : 2.0);
+        if (units_per_piece < 2.5 * 16.0 * (double)c->n_cu) chunked = false;
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor

@@ -50,13 +50,11 @@ struct SeqSet {
     {
         if (!has_n[id]) return false;
         if (id >= npre.size() || npre[id].empty()) return true;   // no counts kept: the contig's flag decides
-        const int64_t len = (int64_t)lens[id];
-        int64_t o_lo = (int64_t)off + std::max<int64_t>(lo, 0), o_hi = std::min<int64_t>((int64_t)off + hi, len - 1);
-        if (o_lo > o_hi) return false;
-        const int64_t f_lo = rc ? len - 1 - o_hi : o_lo, f_hi = rc ? len - 1 - o_lo : o_hi;
-        const std::vector<u32>& pre = npre[id];
-        return pre[(size_t)(f_hi / 256) + 1] != pre[(size_t)(f_lo / 256)];
+        return npre_window_has_n(npre[id].data(), (int64_t)lens[id], rc, off, lo, hi);   // (gamdp_dev.h: shared with the chain kernels)
     }
+    // the same counts on the device, for the chain kernels (all sequences with N in one buffer; nullptr for a sequence without)
+    u32* d_npre = nullptr;
+    std::vector<const u32*> dev_npre;
     std::vector<DevSeq> fwd;
     mutable std::vector<DevSeq> rc;  // reverse complements, uploaded on first use
     mutable std::vector<u32*> rc_allocs;

@@ -54,13 +54,14 @@ __shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise
 #include "kernel_finish.inc"
 
 // the device's side of gamdp_ctx_launch_info: lane 0 of a unit counts what the unit did
-__device__ __forceinline__ void count_unit(const LaunchParams& p, const int lane, const bool dirfree, const bool packed_top, const bool mixed_top)
+__device__ __forceinline__ void count_unit(const LaunchParams& p, const int lane, const bool dirfree, const bool packed_top, const bool mixed_top, const bool top_wanted = false)
 {
     if (p.stats != nullptr && lane == 0) {
         atomicAdd(p.stats + LS_UNITS, 1u);
         if (dirfree) atomicAdd(p.stats + LS_DIRFREE, 1u);
         if (packed_top) atomicAdd(p.stats + LS_PACKED_TOP, 1u);
         if (mixed_top) atomicAdd(p.stats + LS_PACKED_TOP_MIXED, 1u);
+        if (top_wanted) atomicAdd(p.stats + LS_TOP_WANTED, 1u);   // a unit with a packed range whose tasks hold blocks with pos <= 0 cells behind the ramp (what the packed top blocks are for)
     }
 }
 
@@ -388,20 +389,23 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     // The top blocks (cells with pos <= 0: rows < band + 1 - begin_a) go packed as well when the two tasks share begin_a -- the
     // pos == -1 cell is then the same cell (r, c) of a lane for both -- and neither is a force_start call: from the first group
     // start behind the ramp (every lane past its row 1) and one tagged block, pair_top_range() up to the first plain block
+    // Round 5: tasks that differ in begin_a, or force_start calls, take the per-task form of the same blocks (MIXED / FS instances of
+    // pair_top_range: the calls of the live driver); a task whose band has left the triangle earlier runs plain packed blocks there.
     int top_from = 0, top_to = 0;
-    if (GAMDP_PACKED_TOP && hi > lo && ta.begin_a == tb.begin_a && !ta.fs && !tb.fs && !(p.flags & LP_NO_PACKED_TOP)) {
+    const bool top_mixed = ta.begin_a != tb.begin_a || ta.fs || tb.fs, top_fs = ta.fs || tb.fs;
+    if (GAMDP_PACKED_TOP && hi > lo && !(p.flags & LP_NO_PACKED_TOP) && !(top_mixed && (p.flags & LP_NO_PACKED_TOP_MIXED))) {
         const int after_ramp = (pa.LE + 1 + ROWS - 1) / ROWS;   // first block with tau0 - LE >= 1
         top_from = (after_ramp + 1 + 3) & ~3;
-        top_to = max(pa.b0, pb.b0);                              // (equal: same begin_a, same band)
+        top_to = max(pa.b0, pb.b0);                              // (the first block without pos <= 0 cells in either task)
         // ... top blocks and nothing else: a call whose end_a lies inside the band's first rows has its pos == end_a anti-diagonal
         // (an END capture) in the same blocks
         bool only_top = top_from < top_to && top_to <= lo;
-        for (int b = top_from; only_top && b < top_to; ++b) only_top = plan_mode(pa, b) == M_TOP && plan_mode(pb, b) == M_TOP;
+        for (int b = top_from; only_top && b < top_to; ++b) only_top = !(plan_mode(pa, b) & M_END) && !(plan_mode(pb, b) & M_END);
         if (only_top) lo = top_from;
         else top_from = top_to = 0;
     }
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
-    count_unit(p, lane, hi > lo, top_to > top_from, false);
+    count_unit(p, lane, hi > lo, top_to > top_from, top_to > top_from && top_mixed, hi > 0 && max(pa.b0, pb.b0) > (((pa.LE + 1 + ROWS - 1) / ROWS + 1 + 3) & ~3));
     if (p.prio_R != 0 && qi >= p.prio_from) {
         ta.prio_R = tb.prio_R = (int)p.prio_R;
         ta.prio_nblk = tb.prio_nblk = max(pa.nblk, pb.nblk);
@@ -414,7 +418,12 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : pb.nblk, lane);
     if (hi > lo) {
         int from = lo;
-        if (top_to > top_from) { pair_top_range<C, CE>(&sta, &stb, &ta, &tb, top_from, top_to, lane); from = top_to; }
+        if (top_to > top_from) {
+            if (!top_mixed) pair_top_range<C, CE>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            else if (!top_fs) pair_top_range<C, CE, 64, true, false>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            else pair_top_range<C, CE, 64, true, true>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            from = top_to;
+        }
         pair_range<C, CE, false>(&sta, &stb, &ta, &tb, from, mid, lane);
         if (hi > mid) pair_range<C, CE, true>(&sta, &stb, &ta, &tb, mid, hi, lane);
         single_resume<C, HASN, true>(&sta, &ta, hi, lane);
@@ -583,20 +592,19 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || quad_or((int)((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE))) lo = mid = hi = 0;
     // packed top blocks (see run_pair): all eight tasks share begin_a, none is a force_start call
     int top_from = 0, top_to = 0;
-    if (GAMDP_PACKED_TOP && hi > lo && !(p.flags & LP_NO_PACKED_TOP)) {
-        const int bmax = quad_max(max(ta.begin_a, tb.begin_a)), bmin = quad_min(min(ta.begin_a, tb.begin_a));
-        if (bmax == bmin && !quad_or((int)(ta.fs || tb.fs))) {
-            const int after_ramp = (uni(pa.LE) + 1 + ROWS - 1) / ROWS;
-            top_from = (after_ramp + 1 + 3) & ~3;
-            top_to = quad_max(max(pa.b0, pb.b0));
-            int only_top = (top_from < top_to && top_to <= lo) ? 1 : 0;
-            for (int b = top_from; only_top && b < top_to; ++b) only_top = quad_or((plan_mode(pa, b) != M_TOP || plan_mode(pb, b) != M_TOP) ? 1 : 0) ? 0 : 1;
-            if (only_top) lo = top_from;
-            else top_from = top_to = 0;
-        }
+    const bool top_fs = quad_or((int)(ta.fs || tb.fs)) != 0;
+    const bool top_mixed = top_fs || quad_max(max(ta.begin_a, tb.begin_a)) != quad_min(min(ta.begin_a, tb.begin_a));   // (run_pair: the per-task form)
+    if (GAMDP_PACKED_TOP && hi > lo && !(p.flags & LP_NO_PACKED_TOP) && !(top_mixed && (p.flags & LP_NO_PACKED_TOP_MIXED))) {
+        const int after_ramp = (uni(pa.LE) + 1 + ROWS - 1) / ROWS;
+        top_from = (after_ramp + 1 + 3) & ~3;
+        top_to = (quad_max(max(pa.b0, pb.b0)) + 3) & ~3;   // (to a group boundary: the plain packed range re-centres by groups, PairFmt::GRP; a block or two past the triangle run here as plain blocks)
+        int only_top = (top_from < top_to && top_to <= lo) ? 1 : 0;
+        for (int b = top_from; only_top && b < top_to; ++b) only_top = quad_or((plan_mode(pa, b) | plan_mode(pb, b)) & M_END) ? 0 : 1;
+        if (only_top) lo = top_from;
+        else top_from = top_to = 0;
     }
     ta.df_lo = tb.df_lo = lo; ta.df_hi = tb.df_hi = hi; ta.df_top = tb.df_top = top_to;
-    count_unit(p, lane, hi > lo, top_to > top_from, false);
+    count_unit(p, lane, hi > lo, top_to > top_from, top_to > top_from && top_mixed, hi > 0 && quad_max(max(pa.b0, pb.b0)) > (((uni(pa.LE) + 1 + ROWS - 1) / ROWS + 1 + 3) & ~3));
     if (p.prio_R != 0 && qi >= p.prio_from) {
         ta.prio_R = tb.prio_R = (int)p.prio_R;
         ta.prio_nblk = tb.prio_nblk = max(nA, nB);
@@ -609,7 +617,12 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, 0, hi > lo ? lo : nB, lane);
     if (hi > lo) {
         int from = lo;
-        if (top_to > top_from) { pair_top_range<C, CE, QL>(&sta, &stb, &ta, &tb, top_from, top_to, lane); from = top_to; }
+        if (top_to > top_from) {
+            if (!top_mixed) pair_top_range<C, CE, QL>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            else if (!top_fs) pair_top_range<C, CE, QL, true, false>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            else pair_top_range<C, CE, QL, true, true>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            from = top_to;
+        }
         pair_range<C, CE, false, QL>(&sta, &stb, &ta, &tb, from, mid, lane);
         if (hi > mid) pair_range<C, CE, true, QL>(&sta, &stb, &ta, &tb, mid, hi, lane);
         single_resume<C, HASN, true, QL>(&sta, &ta, hi, lane);
@@ -702,7 +715,12 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
             const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
             const u32 idx = audit_first + n_dp;
             if (st == 0 && X > (u64)max_x) { overflow = true; break; }   // (the host sized the slot for the chain's longest slave frame: never, unless its arithmetic and this one differ)
-            if (lane == 0) { ChainWin w; w.begin_a = begin_a; w.end_a = end_a; w.begin_b = begin_b; w.end_b = end_b; w.X = (u32)X; w.info = (try_rev ? 1u : 0u) | ((u32)st << 8); cp.win[idx] = w; }
+            // N by window: the cell of THIS call (HASN: one of the chain's contigs holds an N somewhere)
+            bool call_n = false;
+            if constexpr (HASN)
+                call_n = st == 0 && (cp.n_by_contig != 0 || call_touches_n(unip(mb->npre_a), (int64_t)mlen, false, 0, unip(mb->npre_b), (int64_t)slen, try_rev, 0, (int64_t)band,
+                                                                            (int64_t)begin_a, (int64_t)begin_b, (int64_t)X, (int64_t)cp.n_margin));
+            if (lane == 0) { ChainWin w; w.begin_a = begin_a; w.end_a = end_a; w.begin_b = begin_b; w.end_b = end_b; w.X = (u32)X; w.info = (try_rev ? 1u : 0u) | (call_n ? 2u : 0u) | ((u32)st << 8); cp.win[idx] = w; }
 #ifdef GAMDP_DIAG
             if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x1000u | ((u32)st << 16) | (k << 20); cp.out[mi] = o; }   // progress marker (overwritten at the end)
 #endif
@@ -722,7 +740,10 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
                 dt.begin_a = (int32_t)begin_a; dt.begin_b = (int32_t)begin_b;
                 dt.X = (int32_t)X; dt.band = (int32_t)band;
                 dt.flags = 0; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
-                run_task<5, 0, HASN>(dt, p, slot, lane, false);
+                if constexpr (HASN) {
+                    if (call_n) run_task<5, 0, true>(dt, p, slot, lane, false);
+                    else run_task<5, 0, false>(dt, p, slot, lane, false);
+                } else run_task<5, 0, false>(dt, p, slot, lane, false);
 #ifdef GAMDP_DIAG
                 if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = 0x2000u | (k << 20); cp.out[mi] = o; }
 #endif
@@ -856,7 +877,14 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
             const int st = preflight_hd(mlen, slen, band, begin_a, end_a, begin_b, end_b, false, false, &X, &cells);
             const u32 idx = audit_first + n_dp;
             if (st == 0 && X > (u64)max_x) { overflow = true; break; }   // (the host sized the slots for the chain's longest slave frame: never, unless its arithmetic and this one differ)
-            if (lane == 0) { ChainWin w; w.begin_a = begin_a; w.end_a = end_a; w.begin_b = begin_b; w.end_b = end_b; w.X = (u32)X; w.info = (try_rev ? 1u : 0u) | ((u32)st << 8); cp.win[idx] = w; }
+            // N by window: the cell of THIS call (HASN: one of the chain's contigs holds an N somewhere; most frames on a scaffold
+            // do not touch its runs of N).  Same window as the batch path's (gamdp_host.cpp prepare_task); the host's replay derives
+            // the answer once more and compares.
+            bool call_n = false;
+            if constexpr (HASN)
+                call_n = st == 0 && (cp.n_by_contig != 0 || call_touches_n(unip(mb->npre_a), (int64_t)mlen, false, 0, unip(mb->npre_b), (int64_t)slen, try_rev, 0, (int64_t)band,
+                                                                            (int64_t)begin_a, (int64_t)begin_b, (int64_t)X, (int64_t)cp.n_margin));
+            if (lane == 0) { ChainWin w; w.begin_a = begin_a; w.end_a = end_a; w.begin_b = begin_b; w.end_b = end_b; w.X = (u32)X; w.info = (try_rev ? 1u : 0u) | (call_n ? 2u : 0u) | ((u32)st << 8); cp.win[idx] = w; }
             u32 status;
             if (st != 0) {   // settled without a DP, exactly as the host settles it (Ctx::align)
                 DevResult r;
@@ -878,10 +906,13 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
                 dt.alen = (int32_t)mlen; dt.blen = (int32_t)slen;
                 dt.begin_a = (int32_t)begin_a; dt.begin_b = (int32_t)begin_b;
                 dt.X = (int32_t)X; dt.band = (int32_t)band;
-                dt.flags = 0; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
+                dt.flags = call_n ? TF_CALL_N : 0u; dt.res_idx = idx; dt.ops_off = 0; dt.ops_cap = 0;
                 Tk t;
                 t.cancel = role == 2 ? &sy->cancel : nullptr;
-                fill_task<5, 0, HASN>(dt, p, slots + (u64)par * p.slot_words, lane, false, t);
+                if constexpr (HASN) {
+                    if (call_n) fill_task<5, 0, true>(dt, p, slots + (u64)par * p.slot_words, lane, false, t);
+                    else fill_task<5, 0, false>(dt, p, slots + (u64)par * p.slot_words, lane, false, t);
+                } else fill_task<5, 0, false>(dt, p, slots + (u64)par * p.slot_words, lane, false, t);
                 if (lane == 0) { s_mail.tk[par] = t; s_mail.dt[par] = dt; }
                 ++sent;
                 mail_post(&s_mail.filled, sent, lane);   // (after the wavefront's stores: rows, directions, side buffers)
@@ -967,7 +998,10 @@ __device__ __forceinline__ void chain_walker(const LaunchParams& p, const int la
         WalkCarry wc;
         end_cell<5, true>(&s_mail.tk[par], lane, &wc);
         wc.early_seq = w + 1;
-        finish_walk<5, 0, HASN, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
+        if constexpr (HASN) {   // (the walk of a call filled with the N-aware cell counts N as a match; chain_filler says which it was)
+            if ((u32)uni((int)s_mail.dt[par].flags) & TF_CALL_N) finish_walk<5, 0, true, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
+            else finish_walk<5, 0, false, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
+        } else finish_walk<5, 0, false, 64, false, true>(&s_mail.tk[par], &s_mail.dt[par], &p, lane, 0, 0, &wc);
     }
 }
 

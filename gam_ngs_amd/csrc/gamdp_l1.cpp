@@ -29,6 +29,8 @@
 #include "gamdp_internal.h"
 
 namespace gamdp {
+static bool chain_n_by_contig() { static const bool v = std::getenv("GAMDP_N_BY_CONTIG") != nullptr; return v; }
+
 
 // ---- ABlast::findHits ---------------------------------------------------------------------------
 void find_hits(const uint8_t* a, u64 alen, u64 a_start, u64 a_end, const uint8_t* b, u64 blen, u64 b_start, u64 b_end,
@@ -369,6 +371,8 @@ struct ChainRun {
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const ChainOut* dout = nullptr;   // device copy of the ChainOut list (progress markers in the diagnostics build)
+    bool n_by_contig = false;         // the launch ran every call of a chain with N in its contigs on the N-aware cells
+    const SeqSet *ms = nullptr, *ss = nullptr;
     std::chrono::steady_clock::time_point t_launch;
 
     ChainRun() = default;
@@ -547,6 +551,8 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
         x.rows = (u32)std::min<u64>(w[order[q]], 0x7fffffffu);
         x.try_rev = m.try_rev ? 1u : 0u;
         x.has_n = (ms->has_n[in.m_id] || ss->has_n[in.s_id] || diag().force_n) ? 1u : 0u;
+        x.npre_a = (size_t)in.m_id < ms->dev_npre.size() ? ms->dev_npre[in.m_id] : nullptr;
+        x.npre_b = (size_t)in.s_id < ss->dev_npre.size() ? ss->dev_npre[in.s_id] : nullptr;
         for (u32 k = 0; k < in.n_blocks; k++) {
             const gamdp_block& b = m.blk(k);
             hbk[blk_at + k] = DevBlk{b.m_begin, b.m_end, b.s_begin, b.s_end};
@@ -619,10 +625,15 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     cp.skew_call = ~0u;
     if (diag().build) { static const char* const e = std::getenv("GAMDP_DIAG_CHAIN_SKEW"); if (e) cp.skew_call = (u32)std::atoi(e); }
     cp.two_waves = one_wave ? 0u : 1u;
+    // N by window: the chains pick the cell of every call by the bases it touches (+ 64 on either side, as the batch path does);
+    // GAMDP_N_BY_CONTIG=1 / the diagnostics build's GAMDP_DIAG_FORCE_N: by the contigs' flags, as in rounds 3-4
+    cp.n_margin = 64; cp.n_by_contig = (chain_n_by_contig() || diag().force_n) ? 1u : 0u;
+    if (diag().build) { static const char* const e = std::getenv("GAMDP_DIAG_N_WINDOW_SHRINK"); if (e) cp.n_margin = (u32)std::max(0, 64 - std::atoi(e)); }
+    run.n_by_contig = cp.n_by_contig != 0;
     if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (diag().timing) std::fprintf(stderr, "gamdp chain: %zu merge blocks, %llu blocks, %zu piece(s), %.1f MB of scratch (slots of up to %llu words), %llu twins, has_n %d\n", (size_t)n_mb, (unsigned long long)n_blk, pieces.size(), need_scratch * 4e-6, (unsigned long long)slotw_max, (unsigned long long)n_tw, (int)has_n);
-    run.n_mb = n_mb; run.band = band; run.hmb = hmb;
+    run.n_mb = n_mb; run.band = band; run.hmb = hmb; run.ms = ms; run.ss = ss;
     run.hout = (const ChainOut*)(hm + mo_out); run.done = (const volatile u32*)(hm + mo_done); run.haud = (const DevResult*)(hm + mo_aud); run.hwin = (const ChainWin*)(hm + mo_win);
     run.epoch = cp.epoch; run.stream = c->chain_stream; run.dout = cp.out;
     run.t_launch = std::chrono::steady_clock::now();
@@ -681,6 +692,12 @@ int replay_chain(Ctx* cc, const ChainRun& run, Machine& m, const u32 mi)
         if ((w.info & 1u) != (t.b_rc ? 1u : 0u)) return differs("orientation", w.info & 1u, t.b_rc ? 1u : 0u);
         if ((w.info >> 8) != (u32)st) return differs("pre-check status", w.info >> 8, (u64)st);
         if (w.X != (u32)X) return differs("row count", w.X, X);
+        {   // the cell the device picked for this call (N by window): the host's own answer for the same window, with the full margin
+            const bool want_n = st == GAMDP_ST_OK && x.has_n != 0 &&
+                                (run.n_by_contig || run.ms->window_has_n(t.a_id, false, 0, (int64_t)t.begin_a - (int64_t)run.band - 64, (int64_t)t.begin_a + (int64_t)X - 1 + (int64_t)run.band + 64) ||
+                                 run.ss->window_has_n(t.b_id, t.b_rc, 0, (int64_t)t.begin_b - 64, (int64_t)t.begin_b + (int64_t)X - 1 + 64));
+            if (((w.info >> 1) & 1u) != (want_n ? 1u : 0u)) return differs("choice of the N-aware cell", (w.info >> 1) & 1u, want_n ? 1u : 0u);
+        }
         if (st != GAMDP_ST_OK && (rec.flags >> 8) != (u32)st) return differs("record status", rec.flags >> 8, (u64)st);
         gamdp_result r;
         fill_result(rec, cells, r);

@@ -85,7 +85,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 40), ("n_aware", C.c_uint32), ("tasks_per_wavefront", C.c_uint32), ("tasks", C.c_uint32),
                 ("units", C.c_uint32), ("slots", C.c_uint32), ("band_max", C.c_uint32), ("units_dirfree", C.c_uint32),
                 ("units_packed_top", C.c_uint32), ("units_packed_top_mixed", C.c_uint32), ("strips", C.c_uint32),
-                ("piece", C.c_uint32), ("pad_", C.c_uint32), ("rounds", C.c_double), ("kernel_ms", C.c_double)]
+                ("piece", C.c_uint32), ("units_top_wanted", C.c_uint32), ("rounds", C.c_double), ("kernel_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}

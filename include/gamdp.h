@@ -156,7 +156,7 @@ typedef struct gamdp_launch_info {
     uint32_t units_packed_top_mixed; /* ... of those, through the per-task form: calls that differ in begin_a / force_start calls (device) */
     uint32_t strips;                 /* strip re-creations (materialise calls) of the launch's walks (device) */
     uint32_t piece;                  /* piece of a batch that went through in pieces (0 = the whole batch / its first piece) */
-    uint32_t pad_;
+    uint32_t units_top_wanted;       /* units with a packed range whose calls hold blocks with pos <= 0 cells behind the ramp: what packed top blocks are for (device) */
     double rounds;                   /* units / slots */
     double kernel_ms;                /* HIP events on the library's stream */
 } gamdp_launch_info;

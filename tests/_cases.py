@@ -228,3 +228,31 @@ def displaced_path_cases(band, seed=0, n=5200):
             cases.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1,
                               fs=False, fe=False))
     return cases
+
+
+def n_edge_cases(band):
+    """(a, b, begin_a, end_a, begin_b, end_b) with ONE N placed around each edge of what the DP touches: a[begin_a - band ..
+    begin_a + rows - 1 + band] and b[begin_b .. begin_b + rows - 1].  Two shapes: the alignment runs along the band's first column
+    (b is a copy of a from begin_a - band + 1 on) or along its last (a copy from begin_a + band - 1 on), so that the first / last
+    bases of the a range are ON the path; an N there scores 0 where the A in its place in the 2-bit plane would score +5 or -4."""
+    rng = random.Random(8800 + band)
+    out = []
+    rows = 700
+    for shape in ("low", "high"):
+        begin_a = band + 50 if shape == "low" else 40
+        shift = -band + 1 if shape == "low" else band - 1          # b[x] pairs with a[begin_a + shift + x]
+        a0 = rand_seq(rng, begin_a + shift + rows + band + 700)
+        b0 = a0[begin_a + shift: begin_a + shift + rows + 350]     # b is longer than the window on it
+        begin_b, end_b = 0, rows - 1
+        first_a, last_a = begin_a - band, begin_a + rows - 1 + band    # the a range the DP touches
+        spots = [("a", first_a + d) for d in (-400, -321, -257, -66, -65, -64, -2, -1, 0, 1, 2, 3, 9)] + \
+                [("a", last_a + d) for d in (-9, -3, -2, -1, 0, 1, 2, 63, 64, 65, 66, 257, 321, 400)] + \
+                [("b", end_b + d) for d in (-2, -1, 0, 1, 2, 64, 65, 66, 257, 300)] + [("b", d) for d in (0, 1, 2)]
+        for which, p in spots:
+            a, b = list(a0), list(b0)
+            tgt = a if which == "a" else b
+            if p < 0 or p >= len(tgt):
+                continue
+            tgt[p] = "N"
+            out.append(("".join(a).encode(), "".join(b).encode(), begin_a, len(a) - 1, begin_b, end_b, (shape, which, p - (first_a if which == "a" else 0))))
+    return out

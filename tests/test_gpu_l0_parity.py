@@ -262,32 +262,7 @@ def test_reverse_complement_and_suffix_views():
     assert r.key() == o.key() and r.ops == ops
 
 
-def _n_edge_cases(band):
-    """(a, b, begin_a, end_a, begin_b, end_b) with ONE N placed around each edge of what the DP touches: a[begin_a - band ..
-    begin_a + rows - 1 + band] and b[begin_b .. begin_b + rows - 1].  Two shapes: the alignment runs along the band's first column
-    (b is a copy of a from begin_a - band + 1 on) or along its last (a copy from begin_a + band - 1 on), so that the first / last
-    bases of the a range are ON the path; an N there scores 0 where the A in its place in the 2-bit plane would score +5 or -4."""
-    rng = random.Random(8800 + band)
-    out = []
-    rows = 700
-    for shape in ("low", "high"):
-        begin_a = band + 50 if shape == "low" else 40
-        shift = -band + 1 if shape == "low" else band - 1          # b[x] pairs with a[begin_a + shift + x]
-        a0 = _cases.rand_seq(rng, begin_a + shift + rows + band + 700)
-        b0 = a0[begin_a + shift: begin_a + shift + rows + 350]     # b is longer than the window on it
-        begin_b, end_b = 0, rows - 1
-        first_a, last_a = begin_a - band, begin_a + rows - 1 + band    # the a range the DP touches
-        spots = [("a", first_a + d) for d in (-400, -321, -257, -66, -65, -64, -2, -1, 0, 1, 2, 3, 9)] + \
-                [("a", last_a + d) for d in (-9, -3, -2, -1, 0, 1, 2, 63, 64, 65, 66, 257, 321, 400)] + \
-                [("b", end_b + d) for d in (-2, -1, 0, 1, 2, 64, 65, 66, 257, 300)] + [("b", d) for d in (0, 1, 2)]
-        for which, p in spots:
-            a, b = list(a0), list(b0)
-            tgt = a if which == "a" else b
-            if p < 0 or p >= len(tgt):
-                continue
-            tgt[p] = "N"
-            out.append(("".join(a).encode(), "".join(b).encode(), begin_a, len(a) - 1, begin_b, end_b, (shape, which, p - (first_a if which == "a" else 0))))
-    return out
+_n_edge_cases = _cases.n_edge_cases   # (tests/_cases.py: the L1 seam runs the same cases as merge blocks, test_gpu_l1_parity.py)
 
 
 def test_one_n_around_every_edge_of_the_window():
@@ -548,8 +523,9 @@ def _top_block_batches():
     """Batches built for the packed top blocks (pair_top_range): every call of a batch starts at the same begin_a -- 0, inside
     the band's left triangle, at its edge, just past it (no top blocks at all) -- so that whichever two (eight) calls share a
     wavefront qualify; windows on b, ends past the contigs, alignments whose path starts at pos == 0 far down the triangle
-    (a has a long prefix b lacks) or at row 0 far to the right (b has a long prefix a lacks), an early end of a.  Plus one
-    batch of mixed begin_a and one with force_start calls: those wavefronts keep the int32 top blocks."""
+    (a has a long prefix b lacks) or at row 0 far to the right (b has a long prefix a lacks), an early end of a.  Plus batches
+    whose calls DIFFER in begin_a and hold force_start / force_end calls (the calls of the live driver, PctgBuilder.cc:1535-1611,
+    1662-1669): since round 5 those wavefronts take the per-task form of the packed top blocks (pair_top_range<.., MIXED, FS>)."""
     import _cases
     rng = random.Random(4711)
     batches = []
@@ -586,6 +562,25 @@ def _top_block_batches():
             mixed.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=(0, 5, 0, 90)[k % 4], end_a=len(a) - 1, begin_b=0,
                               end_b=len(b) - 1, fs=(k >= 6), fe=False))
         batches.append(mixed)
+        # wavefronts of mixed begin_a (inside the triangle, at its edge, far past it: no top block at all), force_start calls whose
+        # paths enter at pos == 0 beyond row 10 (where a forced start has no left source) and before it, force_end calls, windows on b
+        for rep in range(3):
+            mix = []
+            for k in range(16):
+                n = rng.choice((2600, 3300, 4100)) if band == 512 else rng.choice((900, 1500, 2300, 4100))
+                a, b = _cases.related_pair(rng, n)
+                kind = rng.randrange(5)
+                if kind == 1:
+                    a = _cases.rand_seq(rng, rng.randint(3, band - 20)) + a      # the path enters at pos == 0 some rows down (3 .. band - 20: either side of row 10)
+                elif kind == 2:
+                    b = _cases.rand_seq(rng, rng.randint(3, band - 20)) + b
+                ba = rng.choice((0, 0, 1, 7, 12, band // 3, band - 17, band - 1, band, band + 1, band + 40, 3 * band))
+                ba = min(ba, len(a) - 1)
+                fs = rng.random() < (0.5 if rep == 2 else 0.25)
+                mix.append(dict(a=a.encode(), b=b.encode(), band=band, begin_a=ba, end_a=len(a) - 1 + rng.choice((0, 0, 40)),
+                                begin_b=rng.choice((0, 0, 13, 250)), end_b=len(b) - 1 - rng.choice((0, 0, 7)),
+                                fs=fs, fe=(not fs and rng.random() < 0.2)))
+            batches.append(mix)
     return batches
 
 
@@ -604,7 +599,20 @@ def test_packed_top_blocks():
                 assert r.key() == o.key(), (cs["band"], cs["begin_a"], k, len(cs["a"]), r.key(), o.key())
                 assert (not want_ops) or r.ops == ops, (cs["band"], cs["begin_a"], k)
                 n_ok += o.status == 0
-    assert n_ok >= 150
+    assert n_ok >= 220
+
+
+def test_top_blocks_packed_for_a_shared_begin_only_in_a_fresh_process():
+    """GAMDP_NO_PACKED_TOP_MIXED=1: wavefronts whose calls differ in begin_a or hold a force_start call keep the int32 top blocks
+    (round 4's rule); same results, at both bands and through the eight-task kernel."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_NO_PACKED_TOP_MIXED"):
+        pytest.skip("already inside the child")
+    for extra in ({}, dict(GAMDP_QUAD_MIN="1")):
+        env = dict(os.environ, GAMDP_NO_PACKED_TOP_MIXED="1", **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                            "packed_top_blocks or window_cases"], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (extra, r.stdout[-2500:] + r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])

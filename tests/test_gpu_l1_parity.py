@@ -236,6 +236,54 @@ def test_other_ways_through_a_merge_block_call_in_a_fresh_process(switch):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, **{switch: "1"})
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), os.path.join(here, "test_gpu_gage.py"),
-                        "-k", "merge_blocks_match_oracle or single_merge_block or reference_exception or gage"],
+                        "-k", "merge_blocks_match_oracle or single_merge_block or reference_exception or gage or one_n_around_every_edge_of_a_chain"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
+def _n_edge_scenarios():
+    """tests/_cases.py n_edge_cases as merge blocks of ONE block whose frames are the call's windows: the main chain's call is then
+    exactly that call (PctgBuilder.cc:1652-1677: begin = frame begin, end = begin + frame length - 1) -- one N at every distance around
+    the first and the last base the DP touches on the master and around the slave frame, the alignment running along the band's first
+    or last column so that those bases are on the path."""
+    import _cases
+    scs = []
+    for a, b, ba, ea, bb, eb, tag in _cases.n_edge_cases(150):
+        scs.append(dict(kind="n-edge %s" % (tag,), master=a.decode(), slave=b.decode(), blocks=[(ba, ea, bb, eb, "+", "+", 10)],
+                        tails=(True, True, True, True)))
+    return scs
+
+
+def test_one_n_around_every_edge_of_a_chain_calls_window():
+    """N by window for the merge-block chains (round 5): the chain kernel picks the cell of every call by the bases the call touches
+    (gamdp_kernel.hip chain_filler, gamdp_dev.h call_touches_n), not by the contigs' flags.  A window computed too small would fill a
+    call whose path crosses an N with the N-free cell, which reads an A there: every DP record of every merge block against the oracle's
+    driver, through the device chains (default), the one-wavefront chain kernel and the round loop (children of
+    test_chain_kernel_variants_in_fresh_processes run this test too)."""
+    stats = _check_against_oracle(ctx(), _n_edge_scenarios())
+    assert stats["ok"] + stats["bad"] >= 50, stats
+
+
+def test_a_chain_window_too_small_is_noticed():
+    """Fault injection (diagnostics build, GAMDP_DIAG_N_WINDOW_SHRINK): the chain kernel tests windows 66 + 256 bases too small on either
+    side.  The host's replay derives the choice of cell of every call by itself, with the full margin, and the call must fail loudly
+    ("the device's choice of the N-aware cell is ...") -- never hand back the alignment an N-free cell made of an N."""
+    import os, subprocess, sys
+    if os.environ.get("GAMDP_DIAG_N_WINDOW_SHRINK"):
+        pytest.skip("already inside the child")
+    from test_gpu_l0_parity import DIAG_LIB
+    code = ("import sys; sys.path.insert(0, %r); import test_gpu_l1_parity as T, gam_ngs_amd as gam\n"
+            "from gam_ngs_amd import lib as L\n"
+            "scs = T._n_edge_scenarios(); c = gam.Context(0)\n"
+            "masters = gam.SequenceSet(c, [s['master'].encode() for s in scs]); slaves = gam.SequenceSet(c, [s['slave'].encode() for s in scs])\n"
+            "try:\n"
+            "    gam.PctgBuilder(c, masters, slaves).alignMergeBlocks(T.make_mbs(scs), audit=16)\n"
+            "    print('NO ERROR')\n"
+            "except L.GamdpError as e:\n"
+            "    print('ERROR:', e)\n") % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GAMDP_LIB=DIAG_LIB, GAMDP_DIAG_N_WINDOW_SHRINK=str(64 + 2 + 256))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "ERROR:" in r.stdout and "choice of the N-aware cell" in r.stdout, r.stdout[-2000:] + r.stderr[-1500:]
+    env = dict(os.environ, GAMDP_LIB=DIAG_LIB)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "NO ERROR" in r.stdout, r.stdout[-2000:] + r.stderr[-1500:]

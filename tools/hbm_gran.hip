@@ -106,7 +106,7 @@ int main()
     RUN_PIECES(2, 32, false, true, "rd_32B_of_32B_scatter");
     RUN_PIECES(1, 64, false, true, "rd_16B_of_64B_scatter");
     RUN_PIECES(10, 256, false, true, "rd_160B_of_256B_scatter");
-    { const uint64_t n = touched / 16; CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_dwords<128, false>), grid, block, 0, 0, buf, n, sink); if (report("rd_4B_of_128B_scatter", n * 4)) return 1; }
+    { const uint64_t n = touched / 32; static_assert(128ull * ((1ull << 30) / 32) <= (6ull << 30), "inside the buffer"); CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_dwords<128, false>), grid, block, 0, 0, buf, n, sink); if (report("rd_4B_of_128B_scatter", n * 4)) return 1; }
     { const uint64_t n = touched / 128; CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_line_by_lane, grid, block, 0, 0, buf, n, sink); if (report("rd_128B_line_by_one_lane_8x16B", n * 128)) return 1; }
     // writes
     RUN_PIECES(64, 1024, true, false, "wr_wide_1024B_inorder");
@@ -116,9 +116,9 @@ int main()
     RUN_PIECES(2, 128, true, true, "wr_32B_of_128B_scatter");
     RUN_PIECES(2, 64, true, true, "wr_32B_of_64B_scatter");
     RUN_PIECES(1, 64, true, true, "wr_16B_of_64B_scatter");
-    { const uint64_t np = touched / 160; CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<2, 5120, 80>), grid, block, 0, 0, buf, np); if (report("wr_2x80B_of_5120B_scatter", np * 160)) return 1; }
-    { const uint64_t np = touched / 160; CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<2, 5120 + 48, 80>), grid, block, 0, 0, buf, np); if (report("wr_2x80B_unaligned_scatter", np * 160)) return 1; }
-    { const uint64_t np = touched / 160; CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<2, 8192, 128>), grid, block, 0, 0, buf, np); if (report("wr_2x80B_in_128B_rows_scatter", np * 160)) return 1; }
+    { const uint64_t np = (bytes - 4096) / 5120; CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<2, 5120, 80>), grid, block, 0, 0, buf, np); if (report("wr_2x80B_of_5120B_scatter", np * 160)) return 1; }
+    { const uint64_t np = (bytes - 4096) / (5120 + 48); CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<2, 5120 + 48, 80>), grid, block, 0, 0, buf, np); if (report("wr_2x80B_unaligned_scatter", np * 160)) return 1; }
+    { const uint64_t np = (bytes - 4096) / 8192; CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<2, 8192, 128>), grid, block, 0, 0, buf, np); if (report("wr_2x80B_in_128B_rows_scatter", np * 160)) return 1; }
     { const uint64_t np = touched / (64 * 80); CHK(hipEventRecord(e0)); hipLaunchKernelGGL((k_rows80<64, 5120, 80>), grid, block, 0, 0, buf, np); if (report("wr_64x80B_contiguous", np * 64 * 80)) return 1; }
     CHK(hipDeviceSynchronize());
     return 0;

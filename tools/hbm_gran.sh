@@ -6,8 +6,8 @@ OUT=${1:-gpurun_out/hbm_gran}
 mkdir -p $OUT
 export TMPDIR=/tmp
 [ -x tools/hbm_gran ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/hbm_gran tools/hbm_gran.hip
-tools/hbm_gran > $OUT/plain.log 2>&1
-pass() { local name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- tools/hbm_gran > $OUT/$name.log 2>&1; }
+timeout 120 tools/hbm_gran > $OUT/plain.log 2>&1
+pass() { local name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- tools/hbm_gran > $OUT/$name.log 2>&1; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
