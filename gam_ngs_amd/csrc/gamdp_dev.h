@@ -266,7 +266,7 @@ struct ChainParams {
     DevResult* host_audit; ChainOut* host_out; u32* host_done; u32 epoch;
     ChainWin* host_win;
     u32 skew_call;                 // diagnostics build only (GAMDP_DIAG_CHAIN_SKEW=k): the device starts call k of every first attempt one base late on the slave; ~0u = off
-    u32 n_margin;                  // bases added on either side of a call's window when it is tested for N (64; the diagnostics build can shrink it: GAMDP_DIAG_N_WINDOW_SHRINK, the replay must notice)
+    int32_t n_margin;              // bases added on either side of a call's window when it is tested for N (64; the diagnostics build can shrink it below zero: GAMDP_DIAG_N_WINDOW_SHRINK, the replay must notice)
     u32 n_by_contig;               // 1: every call of a chain whose contigs hold N runs the N-aware cells (GAMDP_N_BY_CONTIG=1, GAMDP_DIAG_FORCE_N)
     u32 two_waves;                 // k_chain2: a workgroup of one filling and several walking wavefronts with chain_slots_per_workgroup() scratch slots of slot_words each
 };

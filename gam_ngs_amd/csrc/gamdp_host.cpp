@@ -635,10 +635,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             u64 ckpt_words = 0, bnd_words = 0;
             const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
             const bool pair = kid == K_P17_CE4 || kid == K_O19_CE15;   // ... and, for the pairs (of tasks / of quads), its own direction words
-            // (the one-task band-150 kernels: GAMDP_NO_DF5=1 keeps their directions, A/B)
-            static const bool no_df5 = std::getenv("GAMDP_NO_DF5") != nullptr;
-            const bool c5 = kid == K_C5_CE0 || kid == K_C5_CE0_N;
-            if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1 || (c5 && kernel_dirfree(kid) && !no_df5)) {
+            if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
                 const u64 cw = (u64)kernel_dir_block_words(kid), nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * (u64)kernel_ckpt_words(kid);
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);

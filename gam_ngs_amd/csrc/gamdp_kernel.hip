@@ -45,9 +45,6 @@ namespace gamdp {
 namespace {
 
 #include "kernel_common.inc"
-#ifdef GAMDP_EXP_PHASES
-__shared__ int g_exp_mat_ticks;   // timing experiment: ticks inside materialise() calls of walk_many
-#endif
 #include "kernel_fill.inc"
 #include "kernel_pair.inc"
 #include "kernel_strip.inc"
@@ -314,15 +311,25 @@ __device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
 template <int C, int CE, bool HASN, bool PK, int NT, int LPT = QL>
 __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 first_task, const Tk& ta, const Tk& tb, const int lane, const bool side_by_side = true)
 {
-    auto task_tk = [&](const int s) -> Tk {
-        if constexpr (LPT == 64) return s ? tb : ta;
-        else return bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
+    // The wave-uniform values of every task, for the out-of-line phases below (end cell, strips, walk): with one DPP row per task
+    // they are gathered ONCE per unit (v_readlane) into LDS -- the boundary staging area, idle from here on -- instead of once per
+    // call into private memory.  (The pair kernel's are wave-uniform to begin with and live in run_pair's frame.)
+    Tk* const lds_tk = reinterpret_cast<Tk*>(s_qbnd);
+    static_assert(LPT == 64 || (size_t)NT * sizeof(Tk) <= sizeof(s_qbnd), "the tasks' values fit the staging area");
+    if constexpr (LPT != 64) {
+#pragma unroll 1
+        for (int s = 0; s < NT; ++s) {
+            const Tk ts = bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
+            if (lane == 0) lds_tk[s] = ts;
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // the LDS writes have landed before anybody reads them through a generic pointer
+    }
+    auto task_tkp = [&](const int s) -> const Tk* {
+        if constexpr (LPT == 64) return s ? &tb : &ta;
+        else return lds_tk + s;
     };
     WalkCarry wcs[NT];
     int skip = 0, padding = 0;
-#ifdef GAMDP_EXP_PHASES
-    const long long tp0 = wall_clock64();
-#endif
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
         const u32 fl = (u32)uni((int)p.tasks[first_task + (u32)s].flags);
@@ -333,37 +340,20 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
             padding |= 1 << s;
             continue;
         }
-        const Tk ts = task_tk(s);
-        end_cell<C>(&ts, lane, &wcs[s]);
+        end_cell<C>(task_tkp(s), lane, &wcs[s]);
         if (fl & TF_WANT_OPS) skip |= 1 << s;                                                   // the edit string takes one step at a time
         if (fl & TF_LIVE_MASK & (TF_DIAG_SKIP_TRACEBACK | TF_DIAG_COUNT_MAT)) skip |= (1 << NT) - 1;  // diagnostics: the one-task walk only
     }
-#ifdef GAMDP_EXP_PHASES
-    const long long tp1 = wall_clock64();
-#endif
     // (with four int32 tasks the side-by-side walk spends as many vector instructions per task as the one-task walk, which
     // keeps its bookkeeping on the scalar unit: measured 6 % slower on 98 304 x 50 kb; eight packed tasks: 4 % faster)
     if constexpr (NT == 8 || LPT == 64)
-        if (side_by_side && skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane);
-#ifdef GAMDP_EXP_PHASES
-    const long long tp2 = wall_clock64();
-    int ncalls = 0;
-    for (int s = 0; s < NT; ++s) ncalls += wcs[s].mat_calls;
-#endif
+        if (side_by_side && skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane, lds_tk);
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
         if ((padding >> s) & 1) continue;
-        const Tk ts = task_tk(s);
         const int lb = (LPT == 64) ? 0 : QL * (s & 3), hs = (LPT == 64) ? s : s >> 2;
-        finish_walk<C, CE, HASN, LPT, PK>(&ts, &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);
+        finish_walk<C, CE, HASN, LPT, PK>(task_tkp(s), &p.tasks[first_task + (u32)s], &p, lane, lb, hs, &wcs[s]);
     }
-#ifdef GAMDP_EXP_PHASES
-    {   // timing experiment: the first task's record carries the phase times of the wavefront (10 ns ticks)
-        const long long tp3 = wall_clock64();
-        DevResult* r = &p.results[p.tasks[first_task].res_idx];
-        if (lane == 0) { r->begin_b = (int)(tp1 - tp0); r->score = (int)(tp2 - tp1); r->n_match = (u32)ncalls; r->length = (u32)(tp3 - tp2); r->first_a = g_exp_mat_ticks; }
-    }
-#endif
 }
 
 template <int C, int CE>
@@ -372,9 +362,6 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     constexpr bool HASN = false;
     const DevTask& da = p.tasks[2 * qi];
     const DevTask& db = p.tasks[2 * qi + 1];
-#ifdef GAMDP_EXP_HWID
-    const long long exp_t0 = wall_clock64();
-#endif
     // slot: [dir A][dir B][side buffers A][side buffers B][packed rows][packed boundaries]
     u32* const sideA = slot + 2 * p.dir_words;
     Tk ta = make_tk(da, p, slot, sideA, slot);
@@ -434,16 +421,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     // (two tasks that share no usable run of fast blocks were each filled with directions: they are walked as they are)
     // end cells, walks, results: one task after the other in long launches, where the scalar walk of one wavefront hides
     // behind the fills of its SIMD's other wavefronts; side by side in launches of at most two rounds (LP_WALK_SIDE_BY_SIDE)
-#ifdef GAMDP_EXP_HWID
-    const long long exp_t1 = wall_clock64();
-#endif
     if (ta.prio_R != 0 || (p.flags >> LP_WALK_PRIO_SHIFT) != 0) set_prio_level((p.flags >> LP_WALK_PRIO_SHIFT) & 3u);
     finish_many<C, CE, HASN, true, 2, 64>(p, 2 * qi, ta, tb, lane, (p.flags & LP_WALK_SIDE_BY_SIDE) != 0);
-#ifdef GAMDP_EXP_HWID
-    // placement experiment (results unusable): task A's record carries when the pair started and when its fill ended
-    if (lane == 0) { DevResult* r = &p.results[da.res_idx]; r->begin_a = (int)(exp_t0 & 0x7fffffff); r->begin_b = (int)(exp_t1 & 0x7fffffff); r->score = 12345; }
-    __syncthreads();
-#endif
 }
 
 #ifndef GAMDP_PAIR_WAVES_PER_SIMD
@@ -581,10 +560,6 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     u32* const side = slot + 2 * p.dir_words;
     Tk ta = make_tk(da, p, slot, side + (u64)sub * 4u * p.ypad, slot);
     Tk tb = make_tk(db, p, slot + p.dir_words, side + (u64)(4 + sub) * 4u * p.ypad, slot);
-#ifdef GAMDP_EXP_PHASES
-    const long long tf0 = wall_clock64();
-    g_exp_mat_ticks = 0;
-#endif
     ta.sshift = tb.sshift = (p.flags & LP_NO_STRIP_SHIFT) ? 0 : strip_shift<C, Strip<QL, true>::SL>(uni(quad_max(max(ta.band, tb.band))));   // one for the wavefront
     const Plan pa = make_plan<C>(ta), pb = make_plan<C>(tb);   // per lane
     const int nA = quad_max(pa.nblk), nB = quad_max(pb.nblk);
@@ -630,14 +605,8 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
         single_resume<C, HASN, true, QL>(&stb, &tb, hi, lane);
         quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, nB, lane);
     }
-#ifdef GAMDP_EXP_PHASES
-    const long long tf1 = wall_clock64();
-#endif
     if (uni(ta.prio_R) != 0 || (p.flags >> LP_WALK_PRIO_SHIFT) != 0) set_prio_level((p.flags >> LP_WALK_PRIO_SHIFT) & 3u);
     finish_many<C, CE, HASN, true, 2 * QT>(p, 8 * qi, ta, tb, lane);
-#ifdef GAMDP_EXP_PHASES
-    if (lane == 0) p.results[p.tasks[8 * qi].res_idx].begin_a = (int)(tf1 - tf0);
-#endif
 }
 
 template <int C, int CE>
@@ -1100,14 +1069,13 @@ int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
 // words per block of the direction image: lane major (LANE_WORDS per lane) in the direction-free kernels
 static_assert(DIRFREE_OK<4, 17, false> && DIRFREE_OK<4, 17, true> && DIRFREE_OK<15, 19, false> && DIRFREE_OK<15, 19, true> &&
-                  DIRFREE_OK<0, 5, false> == (GAMDP_DF5 != 0) && DIRFREE_OK<0, 5, true> == (GAMDP_DF5 != 0) && !DIRFREE_OK<-1, 17, true> && !DIRFREE_OK<-1, 9, true> && !DIRFREE_OK<-1, 5, true>,
+                  !DIRFREE_OK<0, 5, false> && !DIRFREE_OK<0, 5, true> && !DIRFREE_OK<-1, 17, true> && !DIRFREE_OK<-1, 9, true> && !DIRFREE_OK<-1, 5, true>,
               "kernel_dir_block_words() below lists the direction-free kernels by id: keep it in step with DIRFREE_OK");
 int kernel_dir_block_words(int kid)
 {
     switch (kid) {
     case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: return IMG_WORDS<17, true>;
     case K_Q19_CE15: case K_Q19_CE15_N: case K_O19_CE15: return IMG_WORDS<19, true>;
-    case K_C5_CE0: case K_C5_CE0_N: return IMG_WORDS<5, DIRFREE_OK<0, 5, false>>;
     default: return kernel_cols(kid) * 64;
     }
 }
@@ -1122,7 +1090,6 @@ bool kernel_dirfree(int kid)
 {
     switch (kid) {
     case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: case K_O19_CE15: case K_Q19_CE15: case K_Q19_CE15_N: return true;
-    case K_C5_CE0: case K_C5_CE0_N: return GAMDP_DF5 != 0;
     default: return false;
     }
 }

@@ -565,9 +565,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     // launch after the other over the same memory; twins only when everything fits at once.
     const u64 Y = 2ull * band + 1, LE = (Y - 1) / 5;
     const u32 ypad = (u32)(((2 * band + 2 + 63) / 64) * 64);
-    // direction-free fast blocks (one live row per 4 blocks, the boundary values of every 4th lane per block) when the kernel has them
-    static const bool no_df5 = std::getenv("GAMDP_NO_DF5") != nullptr;
-    const bool df = kernel_dirfree(K_C5_CE0_N) && !no_df5;
+    const bool df = kernel_dirfree(K_C5_CE0_N);   // (the chain kernels' 5-column shape keeps a direction per cell: no checkpoint / boundary stores)
     // k_chain2: a filling and two walking wavefronts per merge block; GAMDP_L1_ONE_WAVE=1 keeps the one-wavefront kernel (A/B)
     static const bool one_wave = std::getenv("GAMDP_L1_ONE_WAVE") != nullptr;
     const u64 per_wg = one_wave ? 1 : (u64)chain_slots_per_workgroup();
@@ -628,7 +626,7 @@ int launch_main_chains(Ctx* c, std::vector<Machine>& M, const SeqSet* ms, const 
     // N by window: the chains pick the cell of every call by the bases it touches (+ 64 on either side, as the batch path does);
     // GAMDP_N_BY_CONTIG=1 / the diagnostics build's GAMDP_DIAG_FORCE_N: by the contigs' flags, as in rounds 3-4
     cp.n_margin = 64; cp.n_by_contig = (chain_n_by_contig() || diag().force_n) ? 1u : 0u;
-    if (diag().build) { static const char* const e = std::getenv("GAMDP_DIAG_N_WINDOW_SHRINK"); if (e) cp.n_margin = (u32)std::max(0, 64 - std::atoi(e)); }
+    if (diag().build) { static const char* const e = std::getenv("GAMDP_DIAG_N_WINDOW_SHRINK"); if (e) cp.n_margin = 64 - std::atoi(e); }
     run.n_by_contig = cp.n_by_contig != 0;
     if (hipEventCreate(&run.e0) != hipSuccess) { c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
     if (hipEventCreate(&run.e1) != hipSuccess) { (void)hipEventDestroy(run.e0); c->set_error("hipEventCreate failed"); return GAMDP_EHIP; }
