@@ -328,7 +328,11 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
         if constexpr (LPT == 64) return s ? &tb : &ta;
         else return lds_tk + s;
     };
-    WalkCarry wcs[NT];
+    // ... and so do the carries of the walks (what the end-cell search hands to the walk and a walk that stops early to the one that
+    // finishes it): wave-uniform, 92 B per task, behind the window a strip call keeps its bases in (kernel_strip.inc)
+    WalkCarry wcs_private[LPT == 64 ? NT : 1];
+    static_assert(LPT == 64 || 832 * 4 + (size_t)NT * sizeof(WalkCarry) <= sizeof(s_qbnd), "the walks' carries fit the staging area");
+    WalkCarry* const wcs = (LPT == 64) ? wcs_private : reinterpret_cast<WalkCarry*>(s_qbnd + 832);
     int skip = 0, padding = 0;
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {

@@ -18,11 +18,11 @@ python3 tools/srchash.py > $OUT/${TAG}_source_hash    # the sources these counte
 if [ -z "$EXTRA" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-proxy > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
 else
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-l1 --no-band150 --no-proxy --no-cpu-baseline $EXTRA > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-l1 --no-band150 --no-proxy --no-mixed150 --no-cpu-baseline $EXTRA > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_trace.log
 fi
 pmc() {  # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-l1 --no-band150 --no-proxy $EXTRA > $OUT/${TAG}_$name.log 2>&1
+    rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-l1 --no-band150 --no-proxy --no-mixed150 $EXTRA > $OUT/${TAG}_$name.log 2>&1
 }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
