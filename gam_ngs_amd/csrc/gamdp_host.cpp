@@ -571,7 +571,9 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             for (u32 i : g) {
                 const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
                 prep[i].kid = to;
-                prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1) * (u64)kernel_dir_block_words(to);
+                // (+ 3 blocks: the packed range of a wavefront ends behind its longest task, rounded up to a group, and a strip of the
+                // last group writes the direction words of the whole group -- run_octo)
+                prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1 + 3) * (u64)kernel_dir_block_words(to);
             }
             groups[to] = std::move(g);
             g.clear();
@@ -585,7 +587,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         static const bool no_pair = std::getenv("GAMDP_NO_PAIR") != nullptr;
         auto& g = groups[K_C17_CE4];
         if (!no_pair && !diag_no_dirfree && g.size() >= 2) {
-            for (u32 i : g) prep[i].kid = K_P17_CE4;   // same C and LE: dir_words stay
+            for (u32 i : g) { prep[i].kid = K_P17_CE4; prep[i].dir_words += 3ull * (u64)kernel_dir_block_words(K_P17_CE4); }   // same C and LE; + 3 blocks as for the eight-task kernel above
             groups[K_P17_CE4] = std::move(g);
             g.clear();
         }

@@ -377,6 +377,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     // ... followed, still packed, by the blocks up to where the first task leaves its fast + end run
     int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
+    // ... and on over the last rows of both tasks, to the end of the longer one rounded up to a group (run_octo has the argument)
+    if (hi > lo && pa.b2 == pa.nblk && pb.b2 == pb.nblk && abs(pa.nblk - pb.nblk) <= 64) hi = (max(pa.nblk, pb.nblk) + 3) & ~3;
     // The top blocks (cells with pos <= 0: rows < band + 1 - begin_a) go packed as well when the two tasks share begin_a -- the
     // pos == -1 cell is then the same cell (r, c) of a lane for both -- and neither is a force_start call: from the first group
     // start behind the ramp (every lane past its row 1) and one tagged block, pair_top_range() up to the first plain block
@@ -417,10 +419,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
         }
         pair_range<C, CE, false>(&sta, &stb, &ta, &tb, from, mid, lane);
         if (hi > mid) pair_range<C, CE, true>(&sta, &stb, &ta, &tb, mid, hi, lane);
-        single_resume<C, HASN, true>(&sta, &ta, hi, lane);
-        tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane);
-        single_resume<C, HASN, true>(&stb, &tb, hi, lane);
-        tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, pb.nblk, lane);
+        if (hi < pa.nblk) { single_resume<C, HASN, true>(&sta, &ta, hi, lane); tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, pa.nblk, lane); }
+        if (hi < pb.nblk) { single_resume<C, HASN, true>(&stb, &tb, hi, lane); tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, pb.nblk, lane); }
     }
     // (two tasks that share no usable run of fast blocks were each filled with directions: they are walked as they are)
     // end cells, walks, results: one task after the other in long launches, where the scalar walk of one wavefront hides
@@ -569,6 +569,17 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     const int nA = quad_max(pa.nblk), nB = quad_max(pb.nblk);
     int lo = (quad_max(max(pa.b0, pb.b0)) + 1 + 3) & ~3, mid = quad_min(min(pa.b1, pb.b1)) & ~3, hi = quad_min(min(pa.b2, pb.b2)) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || quad_or((int)((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE))) lo = mid = hi = 0;
+    // The end blocks of the packed range run on over the last rows of EVERY task of the wavefront (round 5): rows past a task's last
+    // row compute on padding and only ever feed rows past it (pair_range<END>: nothing is masked, the last row and the pos == end_a
+    // cells are taken as they pass), so the range ends behind the longest task, rounded up to a group -- not at the last group
+    // boundary before the shortest task's end with the rest left to the int32 code, one quad after the other (3 - 5 blocks per quad:
+    // 5 % of a 5 kb task).  When every task's end run reaches its own last block and the tasks end within 64 blocks of each other:
+    // what a task reads past its end then stays inside the sequences' padding (SEQ_PAD_BASES), its direction image has three blocks
+    // to spare (gamdp_host.cpp).
+    if (hi > lo) {
+        const int nmax = max(nA, nB), nmin = quad_min(min(pa.nblk, pb.nblk));
+        if (!quad_or((pa.b2 != pa.nblk || pb.b2 != pb.nblk) ? 1 : 0) && nmax - nmin <= 64) hi = (nmax + 3) & ~3;
+    }
     // packed top blocks (see run_pair): all eight tasks share begin_a, none is a force_start call
     int top_from = 0, top_to = 0;
     const bool top_fs = quad_or((int)(ta.fs || tb.fs)) != 0;
@@ -604,10 +615,8 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
         }
         pair_range<C, CE, false, QL>(&sta, &stb, &ta, &tb, from, mid, lane);
         if (hi > mid) pair_range<C, CE, true, QL>(&sta, &stb, &ta, &tb, mid, hi, lane);
-        single_resume<C, HASN, true, QL>(&sta, &ta, hi, lane);
-        quad_tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, nA, lane);
-        single_resume<C, HASN, true, QL>(&stb, &tb, hi, lane);
-        quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, nB, lane);
+        if (hi < nA) { single_resume<C, HASN, true, QL>(&sta, &ta, hi, lane); quad_tagged_blocks<C, CE, HASN>(&sta, &ta, pa, hi, nA, lane); }
+        if (hi < nB) { single_resume<C, HASN, true, QL>(&stb, &tb, hi, lane); quad_tagged_blocks<C, CE, HASN>(&stb, &tb, pb, hi, nB, lane); }
     }
     if (uni(ta.prio_R) != 0 || (p.flags >> LP_WALK_PRIO_SHIFT) != 0) set_prio_level((p.flags >> LP_WALK_PRIO_SHIFT) & 3u);
     finish_many<C, CE, HASN, true, 2 * QT>(p, 8 * qi, ta, tb, lane);
