@@ -637,7 +637,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             u64 ckpt_words = 0, bnd_words = 0;
             const u32 tpw = (u32)kernel_tasks_per_wave(kid);  // tasks per wavefront: each has its own side buffers
             const bool pair = kid == K_P17_CE4 || kid == K_O19_CE15;   // ... and, for the pairs (of tasks / of quads), its own direction words
-            if (kid == K_C17_CE4 || kid == K_C17_CE4_N || tpw > 1) {
+            if (tpw > 1 || kernel_dirfree(kid)) {   // (the tuned band-512 kernels, the multi-task kernels, the generic kernels with 9 / 17 columns per lane)
                 const u64 cw = (u64)kernel_dir_block_words(kid), nblk = dirw / cw + 1;
                 ckpt_words = (nblk / 4 + 2) * (u64)kernel_ckpt_words(kid);
                 bnd_words = (nblk + 4) * (u64)kernel_bnd_words(kid);
@@ -805,7 +805,6 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 r.tasks = (u32)launch_items[li].size();
                 r.units = L.count / r.tasks_per_wavefront;
                 r.slots = L.n_slots;
-                r.band_max = (L.ypad - 2) / 2;   // (rounded up to the side buffers' stride; the exact band follows below)
                 u32 bm = 0;
                 for (u32 i : launch_items[li]) bm = std::max<u32>(bm, (u32)prep[i].dt.band);
                 r.band_max = bm;

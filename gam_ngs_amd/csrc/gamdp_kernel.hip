@@ -1082,13 +1082,15 @@ int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
 // words per block of the direction image: lane major (LANE_WORDS per lane) in the direction-free kernels
 static_assert(DIRFREE_OK<4, 17, false> && DIRFREE_OK<4, 17, true> && DIRFREE_OK<15, 19, false> && DIRFREE_OK<15, 19, true> &&
-                  !DIRFREE_OK<0, 5, false> && !DIRFREE_OK<0, 5, true> && !DIRFREE_OK<-1, 17, true> && !DIRFREE_OK<-1, 9, true> && !DIRFREE_OK<-1, 5, true>,
+                  !DIRFREE_OK<0, 5, false> && !DIRFREE_OK<0, 5, true> && DIRFREE_OK<-1, 17, true> && DIRFREE_OK<-1, 9, true> && !DIRFREE_OK<-1, 5, true> && !DIRFREE_OK<-1, 3, true>,
               "kernel_dir_block_words() below lists the direction-free kernels by id: keep it in step with DIRFREE_OK");
 int kernel_dir_block_words(int kid)
 {
     switch (kid) {
     case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: return IMG_WORDS<17, true>;
     case K_Q19_CE15: case K_Q19_CE15_N: case K_O19_CE15: return IMG_WORDS<19, true>;
+    case K_GEN_C17: return IMG_WORDS<17, true>;
+    case K_GEN_C9: return IMG_WORDS<9, true>;
     default: return kernel_cols(kid) * 64;
     }
 }
@@ -1102,7 +1104,7 @@ int kernel_ckpt_words(int kid)
 bool kernel_dirfree(int kid)
 {
     switch (kid) {
-    case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: case K_O19_CE15: case K_Q19_CE15: case K_Q19_CE15_N: return true;
+    case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: case K_O19_CE15: case K_Q19_CE15: case K_Q19_CE15_N: case K_GEN_C9: case K_GEN_C17: return true;
     default: return false;
     }
 }

@@ -642,6 +642,32 @@ def test_window_cases_on_long_pairs(seed):
         c.set_arena_bytes(0)
 
 
+@pytest.mark.parametrize("band", [129, 160, 200, 256, 287, 288, 300, 400, 500, 543])
+def test_generic_bands_on_long_pairs(band):
+    """Bands other than the two tuned ones: the generic kernels with 9 (bands 160 - 287) and 17 columns per lane (288 - 543) fill their fast
+    blocks without directions since round 5 (band 129: 5 columns per lane, a direction per cell as before) -- a RUNTIME (lane, column) for the band's last column in the direction-free cell
+    (do_block_df, kill_c) and in the strips (materialise, CE < 0).  Windowed 0.6 - 14 kb cases (N, force flags, early end_a) and paths
+    k columns off the band's middle from one band edge to the other -- the last ones run inside the strip that holds the band's
+    last column and the dead lanes behind it; summaries and edit strings against the oracle.  (The short random cases of
+    test_random_cases_vs_oracle never reach a direction-free range.)"""
+    cases = _cases.window_cases(band, band, count=24) + _cases.displaced_path_cases(band, n=2600)
+    n = 0
+    for want_ops in (False, True):
+        res = run_cases(cases, want_ops=want_ops)
+        for k, (cs, r) in enumerate(zip(cases, res)):
+            o, ops = oracle_for(cs, want_ops)
+            if o.status == O.INVALID:
+                continue
+            n += 1
+            assert r.key() == o.key(), (band, k, {x: v for x, v in cs.items() if x not in ("a", "b")}, len(cs["a"]), len(cs["b"]), r.key(), o.key())
+            assert (not want_ops) or r.ops == ops, (band, k)
+    assert n >= 60
+    info = ctx().launch_info()
+    cols = next(c for c in (2, 3, 5, 9, 17) if 2 * band + 1 <= c * 64)     # gamdp_host.cpp pick_kernel
+    assert {r["kernel"] for r in info} == {"k_align<%d,-1,true>" % cols}, info
+    assert sum(r["units_dirfree"] for r in info) >= (20 if cols >= 9 else 0), info      # the long ones did run a direction-free range
+
+
 def test_paths_in_every_strip():
     """tests/_cases.py displaced_path_cases: alignments that run k columns off the middle of the band, from one band edge to the
     other -- every strip of the direction-free kernels gets a walk, the strips at the two edges of a task (whose outer lanes
