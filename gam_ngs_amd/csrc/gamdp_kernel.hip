@@ -331,8 +331,8 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
     // ... and so do the carries of the walks (what the end-cell search hands to the walk and a walk that stops early to the one that
     // finishes it): wave-uniform, 92 B per task, behind the window a strip call keeps its bases in (kernel_strip.inc)
     WalkCarry wcs_private[LPT == 64 ? NT : 1];
-    static_assert(LPT == 64 || 832 * 4 + (size_t)NT * sizeof(WalkCarry) <= sizeof(s_qbnd), "the walks' carries fit the staging area");
-    WalkCarry* const wcs = (LPT == 64) ? wcs_private : reinterpret_cast<WalkCarry*>(s_qbnd + 832);
+    static_assert(LPT == 64 || 800 * 4 + (size_t)NT * sizeof(WalkCarry) <= sizeof(s_qbnd), "the walks' carries fit the staging area");
+    WalkCarry* const wcs = (LPT == 64) ? wcs_private : reinterpret_cast<WalkCarry*>(s_qbnd + 800);   // (512 + 2 x 144 words: behind a strip call's windows)
     int skip = 0, padding = 0;
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
@@ -350,8 +350,35 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
     }
     // (with four int32 tasks the side-by-side walk spends as many vector instructions per task as the one-task walk, which
     // keeps its bookkeeping on the scalar unit: measured 6 % slower on 98 304 x 50 kb; eight packed tasks: 4 % faster)
-    if constexpr (NT == 8 || LPT == 64)
-        if (side_by_side && skip != (1 << NT) - 1) walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane, lds_tk);
+    if constexpr (NT == 8 || LPT == 64) {
+        if (side_by_side && skip != (1 << NT) - 1) {
+            for (;;) {
+                const u32 need = (u32)uni((int)walk_many<C, CE, HASN, PK, NT, LPT>(&ta, &tb, wcs, skip, lane, lds_tk));
+                if (need == 0) break;
+                if constexpr (LPT != 64) {
+                    // the strips the walks wait for, one task at a time with the whole wavefront on it -- inlined HERE, where nothing
+                    // of the walks is in registers (walk_many)
+#pragma unroll 1
+                    for (u32 rest = need; rest != 0; rest &= rest - 1) {
+                        const int s = __builtin_ctz(rest);
+                        __builtin_amdgcn_s_waitcnt(0);   // (the carries walk_many has just written)
+                        const int q_s = uni(wcs[s].need_q), ghi_s = uni(wcs[s].need_ghi);
+                        materialise_auto<C, CE, HASN, LPT, PK, true>(lds_tk + s, q_s, ghi_s, lane, s >> 2, QL * (s & 3));
+                        // the loads of the walk must see those stores: wait until L2 has them, then drop this CU's L1 lines
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (lane == 0) {
+                            WalkCarry& w = wcs[s];
+                            w.old_q = w.mat_q; w.old_lo = w.mat_lo; w.old_hi = w.mat_hi;
+                            w.mat_q = q_s; w.mat_hi = 4 * ghi_s + 3; w.mat_lo = max(4 * (ghi_s - (Strip<LPT, PK>::NB - 1)), lds_tk[s].df_lo);
+                            w.mat_calls++;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);
+                }
+            }
+        }
+    }
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
         if ((padding >> s) & 1) continue;
