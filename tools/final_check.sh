@@ -15,6 +15,8 @@ b = d["band150"]
 print("band150 %.0f GCUPS frac %.4f traffic/alg %s matches %s VALU/cell %s" % (b["gcups"], b["roofline_frac"], b["traffic_over_algorithmic"], b["profile_matches_source"], b["valu"]["insts_per_cell"]))
 for k in ("strong8_proxy", "strong4_proxy"):
     print(k, {x: d[k][x] for x in d[k] if "gcups" in x or "factor" in x})
+m = d["mixed150"]
+print("mixed150 %.0f GCUPS, %.2f ms per step, %.2f ms kernels, packed-top share %s, verified %s (%s)" % (m["gcups"], m["ms_per_step"], m["kernel_ms_per_step"], m["packed_top_share"], m.get("verified_calls"), m.get("verified_against")))
 l = d["l1"]
 print("l1 %.3f ms per call, %.1f GCUPS, frac %.5f" % (l["ms_per_step"], l["gcups"], l["roofline_frac"]), l["counters"], l["cpu_baseline"])
 PY
