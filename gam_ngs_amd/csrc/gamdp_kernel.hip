@@ -103,6 +103,25 @@ __device__ __forceinline__ Plan make_plan(const Tk& t)
     return pl;
 }
 
+// The direction-free blocks of a GENERIC kernel (CE < 0: any band, the last band column a runtime (lane, column) pair) run through the
+// instance of the tuned fast range whose compile-time edge column is this task's, (Y - 1) % C: there the missing `up` source of
+// the band's last column rides in a constant (do_block_df) instead of a select per cell -- two instructions per cell instead of
+// three.  C - 1 instances per kernel (the column C - 1 case keeps the runtime form); everything else of a generic kernel -- tagged
+// blocks, strips, walk -- stays on its one runtime-edge instance, the data layout is the same.
+template <int C, int CE, bool HASN, bool END>
+__device__ __forceinline__ void df_range(BlockState<C>* st, const Tk* tp, const int from, const int to, const int lane, const int ce_rt_)
+{
+    if constexpr (CE >= 0) fast_range<C, CE, HASN, true, END>(st, tp, from, to, lane);
+    else {
+        const int ce_rt = uni(ce_rt_);
+        bool done = false;
+        static_for<C - 1>([&](auto k) __attribute__((always_inline)) {
+            if (!done && ce_rt == decltype(k)::value) { fast_range<C, decltype(k)::value, HASN, true, END>(st, tp, from, to, lane); done = true; }
+        });
+        if (!done) fast_range<C, -1, HASN, true, END>(st, tp, from, to, lane);
+    }
+}
+
 // ---- the whole task -------------------------------------------------------------------------------
 // phases A and B: row 0 and the sweep; leaves the task's values in t for the end-cell search and the walk
 template <int C, int CE, bool HASN>
@@ -164,11 +183,11 @@ __device__ __forceinline__ void fill_task(const DevTask& dt, const LaunchParams&
                 if (blk < t.df_hi && e > t.df_lo && t.df_hi > t.df_lo) {  // this is the run that holds the direction-free groups
                     if (blk < t.df_lo) fast_range<C, CE, HASN, false>(&st, &t, blk, t.df_lo, lane);
                     const int f_hi = min(t.df_hi, e);  // e = first block after the fast run
-                    fast_range<C, CE, HASN, true>(&st, &t, t.df_lo, f_hi, lane);
+                    df_range<C, CE, HASN, false>(&st, &t, t.df_lo, f_hi, lane, (t.Y - 1) % C);
                     if (f_hi < e) fast_range<C, CE, HASN, false>(&st, &t, f_hi, e, lane);
                     blk = e;
                     if (t.df_hi > e) {  // end blocks of the direction-free range
-                        fast_range<C, CE, HASN, true, true>(&st, &t, e, t.df_hi, lane);
+                        df_range<C, CE, HASN, true>(&st, &t, e, t.df_hi, lane, (t.Y - 1) % C);
                         blk = t.df_hi;
                     }
                     continue;
