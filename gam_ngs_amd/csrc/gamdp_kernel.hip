@@ -334,7 +334,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
     // they are gathered ONCE per unit (v_readlane) into LDS -- the boundary staging area, idle from here on -- instead of once per
     // call into private memory.  (The pair kernel's are wave-uniform to begin with and live in run_pair's frame.)
     Tk* const lds_tk = reinterpret_cast<Tk*>(s_qbnd);
-    static_assert(LPT == 64 || (size_t)NT * sizeof(Tk) <= sizeof(s_qbnd), "the tasks' values fit the staging area");
+    static_assert(LPT == 64 || (size_t)NT * sizeof(Tk) <= 512 * sizeof(u32), "the tasks' values fit the staging area in front of a strip call's windows (word 512 on)");
     if constexpr (LPT != 64) {
 #pragma unroll 1
         for (int s = 0; s < NT; ++s) {
