@@ -967,6 +967,8 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     // on, whatever their size.)
     static const long chunk_env = [] { const char* e = std::getenv("GAMDP_CHUNK_MIN"); return e ? (long)std::atoll(e) : -1L; }();
     bool chunked = chunk_env >= 0 && n >= (size_t)chunk_env;
+    bool b150 = false;   // (the band of most of the sampled calls)
+    if (chunked) { size_t n150 = 0, cnt = 0; for (size_t i = 0; i < n; i += 64, cnt++) n150 += tasks[i].band == 150; b150 = 2 * n150 >= cnt; }
     if (chunk_env < 0 && n >= 65536) {
         double est = 0;   // (a sample of the windows is enough: every 64th call)
         size_t cnt = 0;
@@ -983,7 +985,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         // (re-measured with the walk phase's priority in place, which only launches of more than two rounds get: 100 000 x 20 kb at band 150
         // 81 ms in pieces, 72 - 79 whole; 100 000 x 10 kb at band 512 92.5 in pieces, 88.4 whole; 200 000 x 5 kb at band 512 97 - 105 in pieces,
         // 106 - 107 whole; 200 000 x 10 kb at band 150 a tie)
-        const bool b150 = 2 * n150 >= cnt;   // (the band of most of the sampled calls)
+        b150 = 2 * n150 >= cnt;
         chunked = est / (double)std::max<size_t>(1, cnt) < (b150 ? 4.5e6 : 8e6);
         // ... and only if a piece still keeps the chip busy for a few rounds: a piece of a round or less lasts as long as its longest
         // call, four times over (round 5, the driver-shaped batch of 100 000 band-150 calls of 0.2 - 10 k rows: 29.5 ms in four pieces of
@@ -1023,7 +1025,12 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     // that costs ~5 ms per 100 000 tasks -- so the first piece is an eighth of the batch (GAMDP_CHUNK_FIRST_DIV), the other three
     // share the rest; the second thread prepares piece 1 meanwhile.
     static const size_t first_div = [] { const char* e = std::getenv("GAMDP_CHUNK_FIRST_DIV"); const long v = e ? std::atol(e) : 8; return (size_t)std::min(std::max(4L, v), 1024L); }();
-    const size_t pieces = 4, n0 = n / first_div, per = (n - n0 + 2) / 3;
+    // Pieces end on whole rounds (a round = one call set per resident wavefront: 16 per CU, eight calls each at band 150, two otherwise):
+    // calls of one length finish together, and a piece of 3.56 rounds lasts as long as one of four (400 000 x 5 kb at band 150 in pieces
+    // of 1.53 + 3 x 3.56 rounds: 78 ms of kernels for 12.2 rounds of work; in 1 + 4 + 4 + 3.2: thirteen rounds)
+    const size_t round = (size_t)c->n_cu * 16 * (b150 ? 8 : 2);
+    auto whole = [&](size_t v, bool up) { const size_t r = up ? (v + round - 1) / round : v / round; return std::max<size_t>(1, r) * round; };
+    const size_t pieces = 4, n0 = std::min(n, whole(n / first_div, false)), per = whole((n - n0 + 2) / 3, true);
     size_t bound[5] = {0, n0, std::min(n, n0 + per), std::min(n, n0 + 2 * per), n};
     int rc[2] = {0, 0};
     auto worker = [&](int t) noexcept {

@@ -1,5 +1,5 @@
-"""Timing experiment (a library built with -DGAMDP_EXP_PHASES): where the wavefronts of the eight-task band-150 kernel
-spend their time.   GAMDP_LIB=... python tools/phase_times.py [pairs] [len]"""
+"""Timing experiment (a library built with -DGAMDP_EXP_PHASES, see README.md): where the wavefronts of the eight-task band-150
+kernel spend their time, phase by phase.   GAMDP_LIB=... python3 tools/experiments/instrumentation/phase_times.py [pairs] [len]"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import gam_ngs_amd as gam
@@ -17,10 +17,17 @@ out = (L.Result * P)()
 for rep in range(2):
     ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)
 ms, n = ctx.kernel_time()
-# the first task of every octet carries the record; octets are formed in the launch's sorted order, so find them by their fields
-recs = [out[k] for k in range(P) if out[k].begin_a > 1000 and out[k].score > 0 and out[k].length < 10**7]
-n = len(recs)
-f = lambda g: sum(g(r) for r in recs) / max(n, 1) / 100.0
-print("kernel %.1f ms; %d octet records of %d expected" % (ms, n, P // 8))
-print("per octet (us): fill %.0f  end cells %.0f  walk_many %.0f (of which materialise %.0f, %d calls)  tails %.0f" % (
-    f(lambda r: r.begin_a), f(lambda r: r.begin_b), f(lambda r: r.score), f(lambda r: r.first_a), sum(r.n_match for r in recs) / max(n, 1), f(lambda r: r.length)))
+r0 = [out[k] for k in range(P) if out[k].last_b == 0x7e57]
+r1 = [out[k] for k in range(P) if out[k].last_b == 0x7e58]
+n0, n1 = max(len(r0), 1), max(len(r1), 1)
+f0 = lambda g: sum(g(r) for r in r0) / n0 / 100.0
+f1 = lambda g: sum(g(r) for r in r1) / n1 / 100.0
+print("kernels %.1f ms in %d launches; %d + %d unit records of %d units" % (ms, n, len(r0), len(r1), P // 8))
+names = ["setup", "int32 blocks quad A", "int32 blocks quad B", "packed top blocks", "packed plain blocks", "packed end blocks", "int32 tail blocks",
+         "tasks' values to LDS", "end cells", "walk_many", "strips (materialise)", "finish_walk x 8"]
+vals = [f0(lambda r: r.begin_a), f0(lambda r: r.begin_b), f0(lambda r: r.score), f0(lambda r: r.n_match), f0(lambda r: r.length), f0(lambda r: r.first_a),
+        f0(lambda r: r.first_b), f0(lambda r: r.last_a), f1(lambda r: r.begin_a), f1(lambda r: r.begin_b), f1(lambda r: r.score), f1(lambda r: r.n_match)]
+tot = sum(vals)
+for nm, v in zip(names, vals):
+    print("  %-24s %9.1f us  %5.1f %%" % (nm, v, 100.0 * v / max(tot, 1e-9)))
+print("  %-24s %9.1f us; %.1f strip calls per unit" % ("unit", tot, f1(lambda r: r.length) * 100.0))
