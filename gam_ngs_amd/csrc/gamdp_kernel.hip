@@ -458,9 +458,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     if (hi > lo) {
         int from = lo;
         if (top_to > top_from) {
-            if (!top_mixed) pair_top_range<C, CE>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
-            else if (!top_fs) pair_top_range<C, CE, 64, true, false>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
-            else pair_top_range<C, CE, 64, true, true>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            if (!top_fs) pair_top_range<C, CE, 64, false>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            else pair_top_range<C, CE, 64, true>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
             from = top_to;
         }
         pair_range<C, CE, false>(&sta, &stb, &ta, &tb, from, mid, lane);
@@ -654,9 +653,8 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     if (hi > lo) {
         int from = lo;
         if (top_to > top_from) {
-            if (!top_mixed) pair_top_range<C, CE, QL>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
-            else if (!top_fs) pair_top_range<C, CE, QL, true, false>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
-            else pair_top_range<C, CE, QL, true, true>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            if (!top_fs) pair_top_range<C, CE, QL, false>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
+            else pair_top_range<C, CE, QL, true>(&sta, &stb, &ta, &tb, top_from, top_to, lane);
             from = top_to;
         }
         pair_range<C, CE, false, QL>(&sta, &stb, &ta, &tb, from, mid, lane);
