@@ -590,10 +590,12 @@ __device__ __forceinline__ void quad_tagged_blocks(BlockState<C>* st, const Tk* 
             fast_range<C, CE, HASN, false, false, QL>(st, t, blk, e, lane);
             blk = e;
         } else {
-            if (m == M_TOP) slow_block<C, CE, HASN, M_TOP, QL>(st, t, blk, lane);
+            int e = blk + 1;   // a run of top blocks (the ramp): one call
+            while (m == M_TOP && e < to && quad_or(plan_mode(pl, e)) == m) ++e;
+            if (m == M_TOP) slow_block<C, CE, HASN, M_TOP, QL>(st, t, blk, lane, e);
             else if (m == M_END) slow_block<C, CE, HASN, M_END, QL>(st, t, blk, lane);
             else slow_block<C, CE, HASN, M_BOTH, QL>(st, t, blk, lane);
-            ++blk;
+            blk = e;
         }
     }
 }
