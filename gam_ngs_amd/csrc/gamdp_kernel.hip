@@ -297,31 +297,6 @@ __device__ __forceinline__ int quad_min(int v)
 {
     return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-__device__ __forceinline__ int64_t rl64(int64_t v, int src)
-{
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)(u64)v, src), hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), src);
-    return (int64_t)(((u64)hi << 32) | lo);
-}
-template <class P>
-__device__ __forceinline__ P rlp(P p, int src) { return (P)(u64)rl64((int64_t)(u64)p, src); }
-// the values of the task held by lane `src`, in every lane
-__device__ __forceinline__ Tk bcast_tk(const Tk& m, const int src)
-{
-    Tk t;
-    t.a2 = rlp(m.a2, src); t.an = rlp(m.an, src); t.b2 = rlp(m.b2, src); t.bn = rlp(m.bn, src);
-    t.a_base = rl64(m.a_base, src); t.b_base = rl64(m.b_base, src); t.end_a = rl64(m.end_a, src);
-    t.alen = __builtin_amdgcn_readlane(m.alen, src); t.blen = __builtin_amdgcn_readlane(m.blen, src);
-    t.begin_a = __builtin_amdgcn_readlane(m.begin_a, src); t.begin_b = __builtin_amdgcn_readlane(m.begin_b, src);
-    t.X = __builtin_amdgcn_readlane(m.X, src); t.band = __builtin_amdgcn_readlane(m.band, src); t.Y = __builtin_amdgcn_readlane(m.Y, src);
-    t.fs = __builtin_amdgcn_readlane((int)m.fs, src) != 0; t.fe = __builtin_amdgcn_readlane((int)m.fe, src) != 0;
-    t.iA = __builtin_amdgcn_readlane(m.iA, src); t.eaRel = __builtin_amdgcn_readlane(m.eaRel, src);
-    t.dir = rlp(m.dir, src); t.h0row = rlp(m.h0row, src); t.pos0 = rlp(m.pos0, src); t.lastrow = rlp(m.lastrow, src); t.adh = rlp(m.adh, src);
-    t.ckpt = rlp(m.ckpt, src); t.bnd = rlp(m.bnd, src);
-    t.df_lo = __builtin_amdgcn_readlane(m.df_lo, src); t.df_hi = __builtin_amdgcn_readlane(m.df_hi, src); t.df_top = __builtin_amdgcn_readlane(m.df_top, src); t.sshift = __builtin_amdgcn_readlane(m.sshift, src);
-    t.prio_R = t.prio_nblk = 0; t.cancel = nullptr;
-    return t;
-}
-
 #include "kernel_walk.inc"
 
 // end cell, walk and result of the NT tasks of a wavefront: the end cells one task at a time (the whole wavefront scans),
@@ -331,15 +306,22 @@ template <int C, int CE, bool HASN, bool PK, int NT, int LPT = QL>
 __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 first_task, const Tk& ta, const Tk& tb, const int lane, const bool side_by_side = true)
 {
     // The wave-uniform values of every task, for the out-of-line phases below (end cell, strips, walk): with one DPP row per task
-    // they are gathered ONCE per unit (v_readlane) into LDS -- the boundary staging area, idle from here on -- instead of once per
-    // call into private memory.  (The pair kernel's are wave-uniform to begin with and live in run_pair's frame.)
+    // they go to LDS ONCE per unit -- the boundary staging area, idle from here on -- instead of once per call into private
+    // memory.  (The pair kernel's are wave-uniform to begin with and live in run_pair's frame.)
     Tk* const lds_tk = reinterpret_cast<Tk*>(s_qbnd);
     static_assert(LPT == 64 || (size_t)NT * sizeof(Tk) <= 512 * sizeof(u32), "the tasks' values fit the staging area in front of a strip call's windows (word 512 on)");
     if constexpr (LPT != 64) {
-#pragma unroll 1
-        for (int s = 0; s < NT; ++s) {
-            const Tk ts = bcast_tk((PK && (s >> 2)) ? tb : ta, QL * (s & 3));
-            if (lane == 0) lds_tk[s] = ts;
+        // (the first lane of every task row copies its own: ta / tb live in private memory -- the ranges take them by address -- and a
+        // broadcast field by field, v_readlane after a reload each, was ~160 serialised round trips per unit: 160 us of a 5 kb unit's 5.5 ms)
+        if ((lane & (QL - 1)) == 0) {
+            Tk ts = ta;
+            ts.prio_R = ts.prio_nblk = 0; ts.cancel = nullptr;
+            lds_tk[lane >> 4] = ts;
+            if constexpr (PK && NT > QT) {
+                Tk us = tb;
+                us.prio_R = us.prio_nblk = 0; us.cancel = nullptr;
+                lds_tk[QT + (lane >> 4)] = us;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0);   // the LDS writes have landed before anybody reads them through a generic pointer
     }

@@ -19,6 +19,7 @@ for rep in range(2):
 ms, n = ctx.kernel_time()
 r0 = [out[k] for k in range(P) if out[k].last_b == 0x7e57]
 r1 = [out[k] for k in range(P) if out[k].last_b == 0x7e58]
+r2 = [out[k] for k in range(P) if out[k].last_b == 0x7e59]
 n0, n1 = max(len(r0), 1), max(len(r1), 1)
 f0 = lambda g: sum(g(r) for r in r0) / n0 / 100.0
 f1 = lambda g: sum(g(r) for r in r1) / n1 / 100.0
@@ -31,3 +32,6 @@ tot = sum(vals)
 for nm, v in zip(names, vals):
     print("  %-24s %9.1f us  %5.1f %%" % (nm, v, 100.0 * v / max(tot, 1e-9)))
 print("  %-24s %9.1f us; %.1f strip calls per unit" % ("unit", tot, f1(lambda r: r.length) * 100.0))
+f2 = lambda g: sum(g(r) for r in r2) / max(len(r2), 1) / 100.0
+print("  of which: the plain range's blocks %.1f (the rest of that phase: its return), the end range's blocks %.1f; of the values' phase: before the loop %.1f, the loop %.1f"
+      % (f2(lambda r: r.begin_a), f1(lambda r: r.last_a), f1(lambda r: r.first_a), f1(lambda r: r.first_b)))
