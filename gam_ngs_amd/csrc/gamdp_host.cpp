@@ -1028,9 +1028,12 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     // Pieces end on whole rounds (a round = one call set per resident wavefront: 16 per CU, eight calls each at band 150, two otherwise):
     // calls of one length finish together, and a piece of 3.56 rounds lasts as long as one of four (400 000 x 5 kb at band 150 in pieces
     // of 1.53 + 3 x 3.56 rounds: 78 ms of kernels for 12.2 rounds of work; in 1 + 4 + 4 + 3.2: thirteen rounds)
+    // (GAMDP_CHUNK_MIN, the tests' way to send small batches through four pieces on two contexts: the plain split)
     const size_t round = (size_t)c->n_cu * 16 * (b150 ? 8 : 2);
     auto whole = [&](size_t v, bool up) { const size_t r = up ? (v + round - 1) / round : v / round; return std::max<size_t>(1, r) * round; };
-    const size_t pieces = 4, n0 = std::min(n, whole(n / first_div, false)), per = whole((n - n0 + 2) / 3, true);
+    const bool by_rounds = chunk_env < 0;
+    const size_t pieces = 4, n0 = by_rounds ? std::min(n, whole(n / first_div, false)) : n / first_div;
+    const size_t per = by_rounds ? whole((n - n0 + 2) / 3, true) : (n - n0 + 2) / 3;
     size_t bound[5] = {0, n0, std::min(n, n0 + per), std::min(n, n0 + 2 * per), n};
     int rc[2] = {0, 0};
     auto worker = [&](int t) noexcept {

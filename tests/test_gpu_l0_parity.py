@@ -13,6 +13,7 @@ import _oracle as O
 from _gpu import ctx, oracle_for, run_cases
 import gam_ngs_amd as gam
 from gam_ngs_amd import api
+from gam_ngs_amd import lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -436,9 +437,29 @@ def test_pieces_over_two_contexts_in_a_fresh_process():
         pytest.skip("already inside the chunked child")
     env = dict(os.environ, GAMDP_CHUNK_MIN="16")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "random_cases_vs_oracle or medium_pairs or golden_small_cases_summary or begin_a_at or band150_stress"],
+                        "random_cases_vs_oracle or medium_pairs or golden_small_cases_summary or begin_a_at or band150_stress or forced_chunked_batch"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
+
+
+def test_a_forced_chunked_batch_goes_through_four_pieces():
+    """Inside the chunked child only: what the library says it launched carries the pieces' numbers (both contexts were used)."""
+    import os
+    if not os.environ.get("GAMDP_CHUNK_MIN"):
+        pytest.skip("only inside the chunked child")
+    c = ctx()
+    sset = gam.SequenceSet.synthetic(c, 4242, 48, 1500)
+    tasks = (L.Task * 48)()
+    for k in range(48):
+        t = tasks[k]
+        t.a_id, t.b_id, t.band = 2 * k, 2 * k + 1, 150
+        t.begin_a, t.end_a, t.begin_b, t.end_b = 0, 1499, 0, sset.lengths[2 * k + 1] - 1
+    out = (L.Result * 48)()
+    assert c.lib.gamdp_align_batch(c.handle, sset.handle, sset.handle, tasks, 48, out, None) == 0, c.last_error()
+    info = c.launch_info()
+    assert sorted({r["piece"] for r in info}) == [0, 1, 2, 3], info
+    assert sum(r["tasks"] for r in info) == 48 and all(out[k].status == L.ST_OK for k in range(48))
+    sset.close()
 
 
 def test_pairs_of_unequal_tasks_band512():
