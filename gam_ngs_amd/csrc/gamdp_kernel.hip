@@ -407,11 +407,11 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
     // ... and on over the last rows of both tasks, to the end of the longer one rounded up to a group (run_octo has the argument)
     if (hi > lo && pa.b2 == pa.nblk && pb.b2 == pb.nblk && abs(pa.nblk - pb.nblk) <= 64) hi = (max(pa.nblk, pb.nblk) + 3) & ~3;
-    // The top blocks (cells with pos <= 0: rows < band + 1 - begin_a) go packed as well when the two tasks share begin_a -- the
-    // pos == -1 cell is then the same cell (r, c) of a lane for both -- and neither is a force_start call: from the first group
-    // start behind the ramp (every lane past its row 1) and one tagged block, pair_top_range() up to the first plain block
-    // Round 5: tasks that differ in begin_a, or force_start calls, take the per-task form of the same blocks (MIXED / FS instances of
-    // pair_top_range: the calls of the live driver); a task whose band has left the triangle earlier runs plain packed blocks there.
+    // The top blocks (cells with pos <= 0: rows < band + 1 - begin_a) go packed as well: from the first group start behind the ramp
+    // (every lane past its row 1) and one tagged block, pair_top_range() up to the first plain block.  Tasks that differ in begin_a cost
+    // nothing extra there (round 5: the pos == -1 cell is found by a marker in the ring, not by per-lane masks); force_start calls take the
+    // FS instance; a task whose band has left the triangle earlier runs plain packed blocks there.  top_mixed is kept for the launch
+    // record and for GAMDP_NO_PACKED_TOP_MIXED (round 4's rule: such wavefronts through the int32 code -- a second way through the tests).
     int top_from = 0, top_to = 0;
     const bool top_mixed = ta.begin_a != tb.begin_a || ta.fs || tb.fs, top_fs = ta.fs || tb.fs;
     if (GAMDP_PACKED_TOP && hi > lo && !(p.flags & LP_NO_PACKED_TOP) && !(top_mixed && (p.flags & LP_NO_PACKED_TOP_MIXED))) {
@@ -609,10 +609,10 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
         const int nmax = max(nA, nB), nmin = quad_min(min(pa.nblk, pb.nblk));
         if (!quad_or((pa.b2 != pa.nblk || pb.b2 != pb.nblk) ? 1 : 0) && nmax - nmin <= 64) hi = (nmax + 3) & ~3;
     }
-    // packed top blocks (see run_pair): all eight tasks share begin_a, none is a force_start call
+    // packed top blocks (see run_pair)
     int top_from = 0, top_to = 0;
     const bool top_fs = quad_or((int)(ta.fs || tb.fs)) != 0;
-    const bool top_mixed = top_fs || quad_max(max(ta.begin_a, tb.begin_a)) != quad_min(min(ta.begin_a, tb.begin_a));   // (run_pair: the per-task form)
+    const bool top_mixed = top_fs || quad_max(max(ta.begin_a, tb.begin_a)) != quad_min(min(ta.begin_a, tb.begin_a));   // (run_pair: for the launch record and the A/B switch)
     if (GAMDP_PACKED_TOP && hi > lo && !(p.flags & LP_NO_PACKED_TOP) && !(top_mixed && (p.flags & LP_NO_PACKED_TOP_MIXED))) {
         const int after_ramp = (uni(pa.LE) + 1 + ROWS - 1) / ROWS;
         top_from = (after_ramp + 1 + 3) & ~3;
