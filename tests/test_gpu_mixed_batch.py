@@ -65,6 +65,24 @@ def test_driver_shaped_batch_of_16384_calls_through_the_planners_choice():
     sset.close()
 
 
+def test_driver_shaped_batch_with_many_tail_calls():
+    """Half of the calls force their start or their end, contigs of 0.2 - 12 kb: the packed top blocks of force_start calls (a second
+    v_pk_max per cell for the chain, pair_top_range<FS>) and calls that start deep inside the band's left triangle, in wavefronts
+    whose tasks differ in begin_a.  (tools/mixed_stress.py runs the same comparison over more seeds and mixes.)"""
+    c = ctx()
+    seqs, calls = _mixed.mixed_batch(777, 2048, 8, force_frac=0.5, len_lo=200, len_hi=12000)
+    sset = gam.SequenceSet(c, seqs, ascii=False)
+    out = run_batch(c, sset, calls)
+    octo = [r for r in c.launch_info() if r["kernel"] == "k_align_o<19,15>"]
+    assert octo and sum(r["units_packed_top_mixed"] for r in octo) > 500, c.launch_info()   # (the eight-task kernel, top blocks of wavefronts whose calls differ)
+    want = oracle_keys(seqs, calls)
+    bad = [i for i in range(len(calls)) if tuple(out[i].key()) != tuple(want[i])]
+    assert not bad, (len(bad), calls[bad[0]], out[bad[0]].key(), want[bad[0]])
+    assert sum(cl["fs"] for cl in calls) > 3000 and sum(cl["fe"] for cl in calls) > 3000
+    assert sum(1 for k in want if k[0] == O.OK) > 12000
+    sset.close()
+
+
 @pytest.mark.parametrize("n_calls,length,band,want", [
     (12288, 2000, 150, "k_align_o<19,15>"),      # a full batch of N-free band-150 calls of >= 1 536 rows: eight tasks per wavefront
     (12288 - 64, 2000, 150, "k_align<5,0,false>"),   # below 12 288 calls (and 8 k rows): one task per wavefront
