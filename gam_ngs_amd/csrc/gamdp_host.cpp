@@ -562,9 +562,13 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // ... and from 12 288 calls on, not only from a chip-full of eight-task wavefronts (32 768): 16 384 x 5 kb 6.0 -> 5.0 ms, 24 576 x 5 kb
             // 8.7 -> 7.3, 16 384 x 2.5 kb 3.8 - 4.9 -> 3.7 - 3.8; 8 192 x 5 kb: equal
             const size_t avg_rows = rows / g.size();
+            // (end of round 5, with the end / top / ramp blocks of a unit at half their cost: also from 8 192 calls of >= 2.5 k rows and from
+            // 6 144 of >= 4.5 k -- whole calls, one-task against eight-task kernel: 8 192 x 3 kb 2.53 -> 2.19 ms, x 5 kb 3.73 -> 2.79, 10 240 x 5 kb
+            // 4.60 -> 3.72, 6 144 x 5 kb 2.73 -> 2.55; 8 192 x 2 kb and 6 144 x 3 kb: equal; 4 096 calls: the one-task kernel at every length)
             const bool octo = v == 0 && !no_pair150 && !diag_no_dirfree &&
                               (quad_min >= 0 ? g.size() >= (size_t)quad_min
-                                             : ((g.size() >= 12288 && avg_rows >= octo_min_rows) || (g.size() >= 6144 && avg_rows >= 8192)));
+                                             : ((g.size() >= 12288 && avg_rows >= octo_min_rows) || (g.size() >= 8192 && avg_rows >= std::max<size_t>(octo_min_rows, 2560)) ||
+                                                (g.size() >= 6144 && avg_rows >= std::max<size_t>(octo_min_rows, 4608))));
             if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
             const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
             const u64 C = (u64)kernel_cols(to);

@@ -88,6 +88,10 @@ def test_driver_shaped_batch_with_many_tail_calls():
     (12288 - 64, 2000, 150, "k_align<5,0,false>"),   # below 12 288 calls (and 8 k rows): one task per wavefront
     (12288, 1400, 150, "k_align<5,0,false>"),    # 12 288 calls, but under 1 536 rows on average
     (6144, 9000, 150, "k_align_o<19,15>"),       # long contigs: from 6 144 calls on
+    (8192, 3000, 150, "k_align_o<19,15>"),       # ... from 8 192 calls of >= 2.5 k rows
+    (8192, 2000, 150, "k_align<5,0,false>"),
+    (6144, 5000, 150, "k_align_o<19,15>"),       # ... from 6 144 of >= 4.5 k
+    (6144, 4000, 150, "k_align<5,0,false>"),
     (64, 3000, 512, "k_align_p<17,4>"),          # band 512 without N: two tasks per wavefront
     (64, 3000, 500, "k_align<17,-1,true>"),      # any other band: the generic kernels
 ])

@@ -39,4 +39,5 @@ for rep in range(reps):
     ms1, n1 = ctx.kernel_time()
     best = min(best, ms1 - ms0); tot += ms1 - ms0; ms0 = ms1
 chk = sum(out[k].score for k in range(0, P, max(1, P // 4096)))
-print("%-22s %-28s kernels: best %8.2f ms  mean %8.2f ms   call: best %8.2f ms   (checksum %d)" % (tag, shape, best, tot / reps, wall, chk))
+names = "+".join(sorted({r["kernel"] for r in ctx.launch_info()}))
+print("%-22s %-28s kernels: best %8.2f ms  mean %8.2f ms   call: best %8.2f ms   (checksum %d)  %s" % (tag, shape, best, tot / reps, wall, chk, names))
