@@ -558,17 +558,18 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // 6 144 tasks 19.3 against 24.1 ms, 16 384 tasks 32.1 against 41.4 ms (four-task kernel), 4 096 tasks 18.6 against 12.3)
             // (round 4, with the top blocks packed and the strips centred on the band's middle column: from ~1.5 k rows on -- 400 000 x 2 kb
             // 4 450 -> 5 500 GCUPS, x 3 kb 4 980 -> 6 200, x 1 kb 3 300 against 3 100 the other way; GAMDP_OCTO_MIN_ROWS overrides, A/B)
-            static const size_t octo_min_rows = [] { const char* e = std::getenv("GAMDP_OCTO_MIN_ROWS"); return e ? (size_t)std::min(std::max(std::atol(e), 0L), 500000L) : (size_t)1536; }();
+            static const size_t octo_min_rows = [] { const char* e = std::getenv("GAMDP_OCTO_MIN_ROWS"); return e ? (size_t)std::min(std::max(std::atol(e), 0L), 500000L) : (size_t)0; }();
             // ... and from 12 288 calls on, not only from a chip-full of eight-task wavefronts (32 768): 16 384 x 5 kb 6.0 -> 5.0 ms, 24 576 x 5 kb
             // 8.7 -> 7.3, 16 384 x 2.5 kb 3.8 - 4.9 -> 3.7 - 3.8; 8 192 x 5 kb: equal
+            // End of round 5, with the end / top / ramp blocks of a unit at half their cost (whole calls, one-task against eight-task kernel):
+            //   from 16 384 calls on at every length measured (x 0.5 kb 2.34 -> 1.91 ms, x 1 kb 2.51 -> 2.19; 65 536 x 0.5 kb 7.7 -> 6.4, x 1.3 kb 10.8 -> 8.0),
+            //   from 12 288 calls of >= 1 k rows (x 1 kb: equal), from 8 192 of >= 2.5 k (x 3 kb 2.53 -> 2.19, x 5 kb 3.73 -> 2.79; x 2 kb: equal),
+            //   from 6 144 of >= 4.5 k (x 5 kb 2.73 -> 2.55; x 3 kb: equal); 4 096 calls: the one-task kernel at every length.
+            // (GAMDP_OCTO_MIN_ROWS=r: at least r rows on average whatever the count -- A/B, and the tests' way to the other kernel)
             const size_t avg_rows = rows / g.size();
-            // (end of round 5, with the end / top / ramp blocks of a unit at half their cost: also from 8 192 calls of >= 2.5 k rows and from
-            // 6 144 of >= 4.5 k -- whole calls, one-task against eight-task kernel: 8 192 x 3 kb 2.53 -> 2.19 ms, x 5 kb 3.73 -> 2.79, 10 240 x 5 kb
-            // 4.60 -> 3.72, 6 144 x 5 kb 2.73 -> 2.55; 8 192 x 2 kb and 6 144 x 3 kb: equal; 4 096 calls: the one-task kernel at every length)
+            auto tier = [&](size_t calls, size_t min_rows) { return g.size() >= calls && avg_rows >= std::max(min_rows, octo_min_rows); };
             const bool octo = v == 0 && !no_pair150 && !diag_no_dirfree &&
-                              (quad_min >= 0 ? g.size() >= (size_t)quad_min
-                                             : ((g.size() >= 12288 && avg_rows >= octo_min_rows) || (g.size() >= 8192 && avg_rows >= std::max<size_t>(octo_min_rows, 2560)) ||
-                                                (g.size() >= 6144 && avg_rows >= std::max<size_t>(octo_min_rows, 4608))));
+                              (quad_min >= 0 ? g.size() >= (size_t)quad_min : (tier(16384, 384) || tier(12288, 1024) || tier(8192, 2560) || tier(6144, 4608)));
             if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
             const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
             const u64 C = (u64)kernel_cols(to);

@@ -84,9 +84,10 @@ def test_driver_shaped_batch_with_many_tail_calls():
 
 
 @pytest.mark.parametrize("n_calls,length,band,want", [
-    (12288, 2000, 150, "k_align_o<19,15>"),      # a full batch of N-free band-150 calls of >= 1 536 rows: eight tasks per wavefront
-    (12288 - 64, 2000, 150, "k_align<5,0,false>"),   # below 12 288 calls (and 8 k rows): one task per wavefront
-    (12288, 1400, 150, "k_align<5,0,false>"),    # 12 288 calls, but under 1 536 rows on average
+    (12288, 2000, 150, "k_align_o<19,15>"),      # a full batch of N-free band-150 calls of >= 1 k rows: eight tasks per wavefront
+    (12288 - 64, 2000, 150, "k_align<5,0,false>"),   # below 12 288 calls (and 2.5 k rows): one task per wavefront
+    (12288, 900, 150, "k_align<5,0,false>"),     # 12 288 calls, but under 1 k rows on average
+    (16384, 600, 150, "k_align_o<19,15>"),       # from 16 384 calls on: at every length
     (6144, 9000, 150, "k_align_o<19,15>"),       # long contigs: from 6 144 calls on
     (8192, 3000, 150, "k_align_o<19,15>"),       # ... from 8 192 calls of >= 2.5 k rows
     (8192, 2000, 150, "k_align<5,0,false>"),
