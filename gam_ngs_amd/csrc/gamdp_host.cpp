@@ -978,6 +978,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         double est = 0;   // (a sample of the windows is enough: every 64th call)
         size_t cnt = 0;
         size_t n150 = 0;
+        u64 rows_max = 0, rows_sum = 0;
         for (size_t i = 0; i < n; i += 64, cnt++) {
             const gamdp_task& t = tasks[i];
             // rows as the pre-checks will size them (banded_smith_waterman.cc:91-95): end_b clipped to the contig, no wrap of the + 1
@@ -985,6 +986,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
             const u64 eb = blen ? std::min<u64>(t.end_b, blen - 1) : 0;
             const u64 rows = (blen && eb >= t.begin_b) ? std::min<u64>(eb - t.begin_b + 1, 500000) : 0;
             est += (double)rows * (2.0 * t.band + 1.0);
+            rows_max = std::max(rows_max, rows); rows_sum += rows;
             n150 += t.band == 150;
         }
         // (re-measured with the walk phase's priority in place, which only launches of more than two rounds get: 100 000 x 20 kb at band 150
@@ -992,11 +994,17 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         // 106 - 107 whole; 200 000 x 10 kb at band 150 a tie)
         b150 = 2 * n150 >= cnt;
         chunked = est / (double)std::max<size_t>(1, cnt) < (b150 ? 4.5e6 : 8e6);
-        // ... and only if a piece still keeps the chip busy for a few rounds: a piece of a round or less lasts as long as its longest
-        // call, four times over (round 5, the driver-shaped batch of 100 000 band-150 calls of 0.2 - 10 k rows: 29.5 ms in four pieces of
-        // 3 600 wavefronts each -- one round, 8 - 11 ms per piece whatever its work -- against one LPT-balanced launch of three rounds)
+        // ... and only if a piece still keeps the chip busy for a few rounds: a piece of a round or less lasts as long as its longest call,
+        // four times over (the driver-shaped batch of 100 000 band-150 calls of 0.2 - 10 k rows: 26 - 29 ms in pieces of one round, 7 - 10 ms
+        // each, against 16.7 ms in one LPT-balanced launch of three rounds).  Unless the calls are of one length (the longest of the sample
+        // within a quarter of the mean): then pieces of whole rounds (below) lose nothing, and half a round per piece is enough -- 200 000 x 2 kb
+        // 31.1 -> 20.9 ms, 262 144 x 1 kb 33.7 -> 19.9, 131 072 x 2 kb 17.8 -> 14.9, x 5 kb 29.2 -> 26.5, 65 536 x 5 kb at band 512 37.4 -> 35.1.
+        // (GAMDP_CHUNK_MIN_ROUNDS: the bar for both, A/B.)
         const double units_per_piece = (double)n * (7.0 / 24.0) / (b150 ? 8.0 : 2.0);
-        if (units_per_piece < 2.5 * 16.0 * (double)c->n_cu) chunked = false;
+        const bool one_length = (double)rows_max * (double)std::max<size_t>(1, cnt) <= 1.25 * (double)rows_sum;
+        static const double min_rounds_env = [] { const char* e = std::getenv("GAMDP_CHUNK_MIN_ROUNDS"); return e ? std::min(std::max(std::atof(e), 0.0), 1000.0) : -1.0; }();
+        const double min_rounds = min_rounds_env >= 0 ? min_rounds_env : (one_length ? 0.5 : 2.5);
+        if (units_per_piece < min_rounds * 16.0 * (double)c->n_cu) chunked = false;
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor
