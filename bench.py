@@ -81,8 +81,7 @@ def cpu_baseline(length, band, pair_ids):
     import _oracle as O
     from gam_ngs_amd import api
     n = len(pair_ids)
-    # the reference allocates a 410 MB matrix per in-flight 50 kb pair: cap the pool so the host stays safe
-    threads = min(os.cpu_count() or 1, 16)
+    threads, _ = cpu_threads(length, band)
     ref = O.ref()
     keys = []
     if ref is not None and hasattr(ref, "gamref_bench_pairs"):
@@ -102,20 +101,45 @@ def cpu_baseline(length, band, pair_ids):
         keys = [O.ref_key(res[i]) for i in range(n)]
     else:
         contiguous = all(pair_ids[i] == pair_ids[0] + i for i in range(n))
-        if not contiguous:
-            raise SystemExit("the oracle's bench entry takes a contiguous pair range")
         res = (O.OracleResult * n)()
         fn = O.oracle().gamdp_oracle_bench_pairs
         fn.restype = C.c_uint64
         fn.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(O.OracleResult)]
         t0 = time.time()
-        cells = fn(pair_ids[0], n, length, band, threads, res)
+        if contiguous:
+            cells = fn(pair_ids[0], n, length, band, threads, res)
+        else:   # the oracle's bench entry takes a contiguous range: a strided sample goes through pair by pair
+            one = (O.OracleResult * 1)()
+            cells = 0
+            for i, k in enumerate(pair_ids):
+                cells += fn(k, 1, length, band, 1, one)
+                C.memmove(C.byref(res, i * C.sizeof(O.OracleResult)), one, C.sizeof(O.OracleResult))
+            threads = 1
         dt = time.time() - t0
         kind = "port"
         keys = [res[i].key() for i in range(n)]
-    rec = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": threads, "kind": kind,
+    rec = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": threads, "hardware_threads": os.cpu_count() or 1,
+           "cores_cap": cpu_threads(length, band)[1], "kind": kind,
            "sample": "%d of the same synthetic %d bp pairs (band %d), %d threads, %.1f s" % (n, length, band, threads, dt)}
     return rec, keys
+
+
+def cpu_threads(length, band):
+    """Threads of the CPU baseline: every hardware thread of the box (T = hardware_concurrency()), fewer only
+    where the reference's own memory appetite forces it -- it allocates the whole band matrix per in-flight pair (8 B per
+    cell: 410 MB for a 50 kb pair at band 512), so the pool is capped at half of the box's available memory.  Returns
+    (threads, None | the reason for a cap) -- the reason is printed next to `cores` in the line."""
+    hw = os.cpu_count() or 1
+    per_pair = 8 * (length + 1) * (2 * band + 1) + (64 << 20)
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    fit = max(1, int(avail * 0.5 // per_pair)) if avail else hw
+    if fit < hw:
+        return fit, ("%d of %d hardware threads: the reference holds a %d MB matrix per in-flight pair and half of the "
+                     "available memory (%.0f GB) fits %d" % (fit, hw, per_pair >> 20, avail / 2**30, fit))
+    return hw, None
 
 
 def launch_summary(ctx):
@@ -397,6 +421,11 @@ def main():
     ap.add_argument("--l1-genome", type=int, default=2_900_000, help="genome size of the L1 workload (S. aureus: 2.9 Mb)")
     ap.add_argument("--no-band150", action="store_true", help="skip the band-150 record of the same pairs")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong8_proxy / strong4_proxy records")
+    ap.add_argument("--arena-gb", type=float, default=0.0,
+                    help="bound the library's scratch arena per rank (GB); default: the library's own budget, or, with "
+                         "BENCH_SHARE_GPU=1, free HBM / (2 x ranks) so that ranks sharing one GPU cannot starve each other")
+    ap.add_argument("--verify-pairs", type=int, default=128,
+                    help="N > 1: pairs of rank 0's share compared with the CPU path (0 = none); N = 1 verifies the cpu_baseline sample")
     ap.add_argument("--no-mixed150", action="store_true", help="skip the mixed150 record (a driver-shaped batch of 100 000 band-150 calls)")
     args = ap.parse_args()
 
@@ -428,13 +457,20 @@ def main():
         print("bench.py: WARNING: running on the diagnostics build (GAMDP_LIB); not a product measurement", file=sys.stderr)
     ctx = gam.Context(local_rank)
     length, band = args.len, args.band
+    arena_bytes = int(args.arena_gb * 2**30)
+    if share_gpu and world > 1 and not arena_bytes:
+        arena_bytes = int(torch.cuda.mem_get_info(local_rank)[0] // (2 * world))
+    if arena_bytes:
+        ctx.set_arena_bytes(arena_bytes)
 
     def barrier():
+        # (RCCL wants to be told the device of a barrier; gloo takes none)
+        kw = {} if share_gpu else {"device_ids": [local_rank]}
         if world > 1:
-            dist.barrier()
+            dist.barrier(**kw)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(**kw)
 
     def measure(mode, steps, warmup):
         """One timed run in `mode`; returns the numbers of the JSON line (rank 0 uses them)."""
@@ -548,7 +584,7 @@ def main():
             print("bench.py: WARNING: %d pairs came back without an alignment (GAMDP_BENCH_IGNORE_FAILED): NOT a valid measurement"
                   % int(m["bad_all"]), file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
-            n_cpu = min(args.cpu_pairs or 32 * min(os.cpu_count() or 1, 16), m["P"])
+            n_cpu = min(args.cpu_pairs or 512, m["P"])   # ~26 G cell updates: 10 - 15 s of the reference on this box's cores
             # the sample is spread over the whole list (the list order is also the order in which a launch pairs tasks
             # up); only the oracle's own bench entry ("port", no reference build on this box) needs a contiguous range
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -566,6 +602,26 @@ def main():
                                  % (ids[k], rec["kind"], gpu_keys[k], cpu_keys[k], len(diff), len(pos)))
             line["verified_pairs"] = len(pos)   # status, begin, score, #matches, length, first/last match, identity
             line["verified_sample"] = "every %d-th pair of the list" % max(1, (m["P"] - 1) // max(1, len(pos) - 1))
+        if world > 1 and args.verify_pairs and not args.no_cpu_baseline:
+            # N > 1: the line is certified too -- a sample spread over RANK 0's share against the CPU path (the baseline
+            # itself, a timing of the host cores, stays an N = 1 record: N ranks would time the same cores N times)
+            pos = strided_sample(m["P"], min(args.verify_pairs, m["P"]))
+            ids = [m["first"] + k * m["stride"] for k in pos]
+            rec, cpu_keys = cpu_baseline(length, band, ids)
+            all_keys = m["gpu_keys"](m["P"])
+            diff = [j for j, k in enumerate(pos) if tuple(all_keys[k]) != tuple(cpu_keys[j])]
+            if diff:
+                j = diff[0]
+                raise SystemExit("bench.py: rank 0: GPU result of pair %d differs from the CPU %s: %r vs %r (%d of %d differ)"
+                                 % (ids[j], rec["kind"], all_keys[pos[j]], cpu_keys[j], len(diff), len(pos)))
+            line["verified_pairs"] = len(pos)
+            line["verified_against"] = rec["kind"]
+            line["verified_sample"] = "every %d-th pair of rank 0's share (pairs %d, %d, ...)" % (
+                max(1, (m["P"] - 1) // max(1, len(pos) - 1)), m["first"], m["first"] + m["stride"])
+        if arena_bytes:
+            line["config"]["arena_bytes_per_rank"] = arena_bytes
+        if share_gpu and world > 1:
+            line["config"]["note"] = "BENCH_SHARE_GPU=1: %d ranks on ONE GPU over gloo -- a test of the N > 1 path, not a multi-GPU measurement" % world
         if not args.no_band150 and world == 1 and band == 512 and "_keep" in m:
             line["band150"] = band150_record(ctx, m, length, verify=0 if args.no_cpu_baseline else 128)
         if not args.no_proxy and world == 1 and band == 512 and args.scaling == "strong" and args.pairs >= 64:
@@ -581,7 +637,7 @@ def main():
             line["l1"] = bench_l1.run(ctx, genome=args.l1_genome, cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

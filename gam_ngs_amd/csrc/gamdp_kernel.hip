@@ -50,6 +50,16 @@ namespace {
 #include "kernel_strip.inc"
 #include "kernel_finish.inc"
 
+// Timing diagnostics of the chain kernels (when a merge block's workgroup began / ended, on which XCC / CU): the diagnostics build
+// only.  The product kernels read neither the clock nor the hardware id; ChainOut's t_* / hw fields are 0 there.
+#ifdef GAMDP_DIAG
+__device__ __forceinline__ u32 diag_clock() { return (u32)wall_clock64(); }
+__device__ __forceinline__ u32 diag_hw_id() { return ((u32)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | ((u32)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu); }   // XCC_ID | HW_ID
+#else
+__device__ __forceinline__ constexpr u32 diag_clock() { return 0u; }
+__device__ __forceinline__ constexpr u32 diag_hw_id() { return 0u; }
+#endif
+
 // the device's side of gamdp_ctx_launch_info: lane 0 of a unit counts what the unit did
 __device__ __forceinline__ void count_unit(const LaunchParams& p, const int lane, const bool dirfree, const bool packed_top, const bool mixed_top, const bool top_wanted = false)
 {
@@ -309,7 +319,7 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
     // they go to LDS ONCE per unit -- the boundary staging area, idle from here on -- instead of once per call into private
     // memory.  (The pair kernel's are wave-uniform to begin with and live in run_pair's frame.)
     Tk* const lds_tk = reinterpret_cast<Tk*>(s_qbnd);
-    static_assert(LPT == 64 || (size_t)NT * sizeof(Tk) <= 512 * sizeof(u32), "the tasks' values fit the staging area in front of a strip call's windows (word 512 on)");
+    static_assert(LPT == 64 || (size_t)NT * sizeof(Tk) <= QB_TK_WORDS * sizeof(u32), "the tasks' values fit the staging area in front of a strip call's windows (word 512 on)");
     if constexpr (LPT != 64) {
         // (the first lane of every task row copies its own: ta / tb live in private memory -- the ranges take them by address -- and a
         // broadcast field by field, v_readlane after a reload each, was ~160 serialised round trips per unit: 160 us of a 5 kb unit's 5.5 ms)
@@ -330,10 +340,11 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
         else return lds_tk + s;
     };
     // ... and so do the carries of the walks (what the end-cell search hands to the walk and a walk that stops early to the one that
-    // finishes it): wave-uniform, 92 B per task, behind the window a strip call keeps its bases in (kernel_strip.inc)
+    // finishes it): wave-uniform, sizeof(WalkCarry) = 100 B per task, behind the windows a strip call keeps its bases in (kernel_strip.inc; the
+    // layout's offsets are kernel_common.inc's QB_*)
     WalkCarry wcs_private[LPT == 64 ? NT : 1];
-    static_assert(LPT == 64 || 800 * 4 + (size_t)NT * sizeof(WalkCarry) <= sizeof(s_qbnd), "the walks' carries fit the staging area");
-    WalkCarry* const wcs = (LPT == 64) ? wcs_private : reinterpret_cast<WalkCarry*>(s_qbnd + 800);   // (512 + 2 x 144 words: behind a strip call's windows)
+    static_assert(LPT == 64 || QB_CARRY_AT * sizeof(u32) + (size_t)NT * sizeof(WalkCarry) <= sizeof(s_qbnd), "the walks' carries fit the staging area");
+    WalkCarry* const wcs = (LPT == 64) ? wcs_private : reinterpret_cast<WalkCarry*>(s_qbnd + QB_CARRY_AT);
     int skip = 0, padding = 0;
 #pragma unroll 1
     for (int s = 0; s < NT; ++s) {
@@ -388,6 +399,13 @@ __device__ __forceinline__ void finish_many(const LaunchParams& p, const u32 fir
     }
 }
 
+// The packed END range runs on past a task's last row: up to END_OVERRUN_BLOCKS blocks (how far the tasks of a wavefront may end
+// apart) plus a group of 4, and the operand rings look (C - 1) * LPT bases + one block ahead of that.  All of it must stay inside the
+// zero padding every sequence carries (SEQ_PAD_BASES, gamdp_dev.h; padded_bases() in gamdp_host.cpp pads reverse complements too).
+constexpr int END_OVERRUN_BLOCKS = 64;
+template <int C, int LPT_>
+constexpr bool end_overrun_fits() { return (END_OVERRUN_BLOCKS + 4) * ROWS + (C - 1) * LPT_ + 512 + 64 <= SEQ_PAD_BASES; }
+
 template <int C, int CE>
 __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u32* slot, const int lane)
 {
@@ -406,7 +424,8 @@ __device__ __forceinline__ void run_pair(const LaunchParams& p, const u32 qi, u3
     int lo = (max(pa.b0, pb.b0) + 1 + 3) & ~3, mid = min(pa.b1, pb.b1) & ~3, hi = min(pa.b2, pb.b2) & ~3;
     if (!(p.ckpt_off != 0 && mid - lo >= 8) || ((da.flags | db.flags) & TF_LIVE_MASK & TF_NO_DIRFREE)) lo = mid = hi = 0;
     // ... and on over the last rows of both tasks, to the end of the longer one rounded up to a group (run_octo has the argument)
-    if (hi > lo && pa.b2 == pa.nblk && pb.b2 == pb.nblk && abs(pa.nblk - pb.nblk) <= 64) hi = (max(pa.nblk, pb.nblk) + 3) & ~3;
+    static_assert(end_overrun_fits<C, 64>(), "what a task reads past its end in the packed END range stays inside the sequences' padding");
+    if (hi > lo && pa.b2 == pa.nblk && pb.b2 == pb.nblk && abs(pa.nblk - pb.nblk) <= END_OVERRUN_BLOCKS) hi = (max(pa.nblk, pb.nblk) + 3) & ~3;
     // The top blocks (cells with pos <= 0: rows < band + 1 - begin_a) go packed as well: from the first group start behind the ramp
     // (every lane past its row 1) and one tagged block, pair_top_range() up to the first plain block.  Tasks that differ in begin_a cost
     // nothing extra there (round 5: the pos == -1 cell is found by a marker in the ring, not by per-lane masks); force_start calls take the
@@ -607,7 +626,8 @@ __device__ __forceinline__ void run_octo(const LaunchParams& p, const u32 qi, u3
     // to spare (gamdp_host.cpp).
     if (hi > lo) {
         const int nmax = max(nA, nB), nmin = quad_min(min(pa.nblk, pb.nblk));
-        if (!quad_or((pa.b2 != pa.nblk || pb.b2 != pb.nblk) ? 1 : 0) && nmax - nmin <= 64) hi = (nmax + 3) & ~3;
+        static_assert(end_overrun_fits<C, QL>(), "what a task reads past its end in the packed END range stays inside the sequences' padding");
+        if (!quad_or((pa.b2 != pa.nblk || pb.b2 != pb.nblk) ? 1 : 0) && nmax - nmin <= END_OVERRUN_BLOCKS) hi = (nmax + 3) & ~3;
     }
     // packed top blocks (see run_pair)
     int top_from = 0, top_to = 0;
@@ -686,8 +706,8 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_align_q(const Laun
 template <bool HASN>
 __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slot, const int lane)
 {
-    const u32 t_begin = (u32)wall_clock64();
-    const u32 hw_me = ((u32)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | ((u32)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu), hw_other = 0, te0 = 0, te1 = 0, tb2 = 0;   // XCC_ID | HW_ID (timing diagnostics)
+    const u32 t_begin = diag_clock();
+    const u32 hw_me = diag_hw_id(), hw_other = 0, te0 = 0, te1 = 0, tb2 = 0;   // XCC_ID | HW_ID (timing diagnostics)
     const DevMB* mb = unip(cp.mbs + mi);
     const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
@@ -791,7 +811,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         try_rev = !try_rev;
     }
     __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.out[mi] = o; }
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = diag_clock(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.out[mi] = o; }
     // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
@@ -803,7 +823,7 @@ __device__ __forceinline__ void run_chain(const ChainParams& cp, const LaunchPar
         u32* wdst = reinterpret_cast<u32*>(cp.host_win + audit_first);
         const u32 nww = n_dp * (u32)(sizeof(ChainWin) / sizeof(u32));
         for (u32 w = (u32)lane; w < nww; w += 64) wdst[w] = wsrc[w];
-        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = diag_clock(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag
@@ -842,8 +862,8 @@ __global__ __launch_bounds__(64, GAMDP_WAVES_PER_SIMD) void k_chain(const ChainP
 template <bool HASN>
 __device__ __forceinline__ void chain_filler(const ChainParams& cp, const LaunchParams& p, const u32 mi, u32* slots, const int lane, const int role)
 {
-    u32 t_begin = (u32)wall_clock64();
-    u32 hw_me = ((u32)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | ((u32)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu), hw_other = 0, te0 = 0, te1 = 0, tb2 = 0;   // XCC_ID | HW_ID (timing diagnostics)
+    u32 t_begin = diag_clock();
+    u32 hw_me = diag_hw_id(), hw_other = 0, te0 = 0, te1 = 0, tb2 = 0;   // XCC_ID | HW_ID (timing diagnostics)
     const DevMB* mb = unip(cp.mbs + mi);
     const u64 mlen = (u64)uni64((int64_t)mb->mlen), slen = (u64)uni64((int64_t)mb->slen);
     const u64 m_start = (u64)uni64((int64_t)mb->m_start), s_start = (u64)uni64((int64_t)mb->s_start), s_end = (u64)uni64((int64_t)mb->s_end);
@@ -953,7 +973,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         const int me = role - 1;
         if (lane == 0) {
             sy->verdict[me] = state; sy->n[me] = n_dp;
-            sy->hw[me] = hw_me; sy->t_end[me] = (u32)wall_clock64(); if (role == 2) sy->t_begin2 = t_begin;
+            sy->hw[me] = hw_me; sy->t_end[me] = diag_clock(); if (role == 2) sy->t_begin2 = t_begin;
             if (role == 1 && state != 1u) __hip_atomic_store(&sy->cancel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -964,7 +984,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         // fails leaves it to whoever is second
         const bool mine = role == 1 ? (state != 1u || before != 0u) : (before != 0u && (u32)uni((int)__hip_atomic_load(&sy->verdict[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1u);
         if (!mine) {
-            if (role == 2 && lane == 0) { cp.host_out[mi].t_begin2 = t_begin; cp.host_out[mi].t_end_att[1] = (u32)wall_clock64(); }   // (timing diagnostics: a twin that wound down after the chain was handed over)
+            if (role == 2 && lane == 0) { cp.host_out[mi].t_begin2 = t_begin; cp.host_out[mi].t_end_att[1] = diag_clock(); }   // (timing diagnostics: a twin that wound down after the chain was handed over)
             return;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -975,7 +995,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         hw_me = (u32)uni((int)sy->hw[0]); hw_other = (u32)uni((int)sy->hw[1]);
         te0 = (u32)uni((int)sy->t_end[0]); te1 = (u32)uni((int)sy->t_end[1]); tb2 = (u32)uni((int)sy->t_begin2);
     }
-    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.out[mi] = o; }
+    if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = diag_clock(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.out[mi] = o; }
     // hand the chain to the host: records and ChainOut into its pinned mirror, then the flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
@@ -987,7 +1007,7 @@ __device__ __forceinline__ void chain_filler(const ChainParams& cp, const Launch
         u32* wdst = reinterpret_cast<u32*>(cp.host_win + audit_first);
         const u32 nww = n_dp * (u32)(sizeof(ChainWin) / sizeof(u32));
         for (u32 w = (u32)lane; w < nww; w += 64) wdst[w] = wsrc[w];
-        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = (u32)wall_clock64(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
+        if (lane == 0) { ChainOut o; o.n_dp = n_dp; o.state = state; o.t_begin = t_begin; o.t_end = diag_clock(); o.hw = hw_me; o.hw_twin = hw_other; o.t_end_att[0] = te0; o.t_end_att[1] = te1; o.t_begin2 = tb2; o.pad = 0; cp.host_out[mi] = o; }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores above are out before the flag

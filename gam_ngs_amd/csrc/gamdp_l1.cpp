@@ -405,6 +405,8 @@ struct ChainRun {
         c->kernel_ms += k; c->kernel_launches++;
         if (diag().timing) {
             std::fprintf(stderr, "gamdp chain: kernel %.3f ms, launched %.3f ms after the call began\n", k, f);
+        }
+        if (diag().timing && diag().build) {   // (the product kernels read no clock: ChainOut's t_* / hw fields are 0 there)
             // the chains that ended last (the device's 100 MHz clock, relative to the first workgroup's start)
             std::vector<u32> idx(n_mb);
             u32 t0 = hout[0].t_begin;

@@ -5,7 +5,8 @@ set -u
 OUT=${1:-gpurun_out/hbm_gran}
 mkdir -p $OUT
 export TMPDIR=/tmp
-[ -x tools/hbm_gran ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/hbm_gran tools/hbm_gran.hip
+# (rebuilt whenever the source is newer: the binary is not tracked)
+[ tools/hbm_gran -nt tools/hbm_gran.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/hbm_gran tools/hbm_gran.hip
 timeout 120 tools/hbm_gran > $OUT/plain.log 2>&1
 pass() { local name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- tools/hbm_gran > $OUT/$name.log 2>&1; }
 pass fetch FETCH_SIZE
