@@ -121,7 +121,8 @@ enum KernelId : int {
     K_O19_CE15,      // band 150, ACGT only, EIGHT tasks per wavefront: two quads, fast blocks in packed f16
     K_Q19_CE15,      // band 150, ACGT only, FOUR tasks per wavefront (16 lanes x 19 columns each): big batches
     K_Q19_CE15_N,    // the same, N-aware
-    K_GEN_C2, K_GEN_C3, K_GEN_C5, K_GEN_C9, K_GEN_C17,  // any band, N-aware, runtime edge column
+    K_GEN_C2, K_GEN_C3, K_GEN_C5, K_GEN_C9, K_GEN_C17,  // any band up to 543, N-aware, runtime edge column
+    K_WIDE,          // any band beyond that (gamdp_wide.hip): a workgroup per task, the band matrix as int32 in the scratch slot, no throughput target
     K_COUNT
 };
 
@@ -280,6 +281,9 @@ bool kernel_dirfree(int kid);          // its fast blocks can run without direct
 int kernel_dir_block_words(int kid);  // words per block (16 row-times) of a task's direction image
 // launches on `stream`; returns hipError_t as int
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, unsigned dyn_lds, void* stream);
+int launch_wide(const LaunchParams& p, unsigned n_slots, void* stream);   // K_WIDE (gamdp_wide.hip): n_slots workgroups
+unsigned wide_static_lds();
+constexpr int WIDE_WORKGROUPS_PER_CU = 8;
 unsigned kernel_static_lds(int kid);  // static LDS bytes of a variant
 // occupancy hint: resident waves per CU for this variant
 int kernel_waves_per_cu(int kid);

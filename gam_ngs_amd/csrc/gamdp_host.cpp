@@ -354,7 +354,8 @@ static int pick_kernel(int band, bool has_n)
     if (Y <= 3 * 64) return K_GEN_C3;
     if (Y <= 5 * 64) return K_GEN_C5;
     if (Y <= 9 * 64) return K_GEN_C9;
-    return K_GEN_C17;
+    if (Y <= 17 * 64) return K_GEN_C17;
+    return K_WIDE;   // band > 543: gamdp_wide.hip
 }
 
 // fn(lo, hi) over [0, n) on the process's host thread pool (gamdp_hostpool.h: HostPool); batches of a few thousand tasks are not worth a thread
@@ -427,10 +428,13 @@ static int prepare_task(const ITask& it, Prepared& pr)
         has_n = it.sa->window_has_n(it.a_id, it.a_rc, it.a_off, (int64_t)it.begin_a - (int64_t)band - margin, (int64_t)it.begin_a + (int64_t)X - 1 + (int64_t)band + margin) ||
                 it.sb->window_has_n(it.b_id, it.b_rc, it.b_off, (int64_t)it.begin_b - margin, (int64_t)it.begin_b + (int64_t)X - 1 + margin);
     pr.kid = pick_kernel((int)band, has_n);
-    const int C = kernel_cols(pr.kid);
-    const int LE = (int)((Y - 1) / (u64)C);
-    const u64 nblk = (X - 1 + (u64)LE) / 16 + 1;
-    pr.dir_words = nblk * (u64)kernel_dir_block_words(pr.kid);
+    if (pr.kid == K_WIDE) pr.dir_words = X * Y;   // the whole band matrix as int32 (gamdp_wide.hip)
+    else {
+        const int C = kernel_cols(pr.kid);
+        const int LE = (int)((Y - 1) / (u64)C);
+        const u64 nblk = (X - 1 + (u64)LE) / 16 + 1;
+        pr.dir_words = nblk * (u64)kernel_dir_block_words(pr.kid);
+    }
     DevTask& d = pr.dt;
     const DevSeq& da = it.a_rc ? it.sa->rc[it.a_id] : it.sa->fwd[it.a_id];
     const DevSeq& db = it.b_rc ? it.sb->rc[it.b_id] : it.sb->fwd[it.b_id];
@@ -794,8 +798,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         HIPCHK(this, hipStreamSynchronize(stream));
         const double ms_gpu = since(t_gpu);
         if (diag_timing) {
-            std::fprintf(stderr, "libgamdp align: %zu tasks, %zu launches: prepare %.2f ms, plan+stage %.2f ms, upload+kernels+download %.2f ms\n",
-                         n, launches.size(), ms_prep, ms_plan, ms_gpu);
+            // (ctx + the call's begin on the process's steady clock: tools/multi_host_overlap.py lays the host phases of several contexts side by side)
+            std::fprintf(stderr, "libgamdp align: %zu tasks, %zu launches: prepare %.2f ms, plan+stage %.2f ms, upload+kernels+download %.2f ms [ctx %p began %.3f]\n",
+                         n, launches.size(), ms_prep, ms_plan, ms_gpu, (void*)this,
+                         std::chrono::duration<double, std::milli>(t_begin.time_since_epoch()).count());
         }
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
@@ -843,7 +849,8 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 }
             }
         });
-        if (diag_timing) std::fprintf(stderr, "libgamdp align: results %.2f ms\n", since(t_fill));
+        if (diag_timing) std::fprintf(stderr, "libgamdp align: results %.2f ms [ctx %p began %.3f]\n", since(t_fill), (void*)this,
+                                      std::chrono::duration<double, std::milli>(t_fill.time_since_epoch()).count());
     }
     return 0;
 }

@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -12,42 +13,55 @@
 
 namespace gamdp {
 
-// The parallel loops of a batch call: fn(lo, hi) over [0, n) on up to 16 host threads.
-// The threads are the process's own and stay: starting and joining 15 threads cost a parallel loop 0.5 - 0.8 ms, four
-// loops per batch call.  One parallel loop at a time: a second caller (the other thread of a batch that goes through in pieces, the
-// host thread of another device) waits its turn when its loop is large -- every loop then still runs on all threads, one after
-// the other -- and runs a small loop itself, on its own thread, instead of waiting.
+// The parallel loops of a batch call: fn(lo, hi) over [0, n) in up to kWidth parts.
+// The threads are the process's own and stay (starting and joining 15 threads cost a parallel loop 0.5 - 0.8 ms, four loops per batch
+// call).  SEVERAL LOOPS RUN AT ONCE (round 6): the host threads of the D devices of a gamdp_multi call, or the two threads of a
+// batch that goes through in pieces, each post their loop as a job; the workers take parts from the jobs in turn, every caller
+// works on its own job, so the host phases of D contexts overlap like the reference's N independent workers
+// (lib/src/pctg/ThreadedBuildPctg.cc:150-175) instead of queueing behind one another.  A loop alone still runs kWidth wide (the
+// loops are memory-bound: wider bought nothing); the pool holds up to kMaxWorkers threads, i.e. four loops at full width.
 class HostPool {
 public:
     static HostPool& get() { static HostPool p; return p; }
+    static constexpr unsigned kWidth = 16;        // parts of one loop = threads a lone loop runs on
+    static constexpr unsigned kMaxWorkers = 63;   // pool threads (beside the callers)
     template <class F>
     void run(size_t n, F& fn)
     {
-        if (workers_.empty()) { fn((size_t)0, n); return; }
-        std::unique_lock<std::mutex> one(use_, std::try_to_lock);
-        if (!one.owns_lock()) {
-            if (n < kWaitFrom) { fn((size_t)0, n); return; }
-            one.lock();
-        }
-        const unsigned parts = (unsigned)workers_.size() + 1;
-        auto body = [&](unsigned k) { fn(n * k / parts, n * (k + 1) / parts); };
+        if (workers_.empty() || n < 2) { fn((size_t)0, n); return; }
+        const unsigned parts = (unsigned)std::min<size_t>(std::min<size_t>(kWidth, workers_.size() + 1), n);
+        std::function<void(unsigned)> body = [&fn, n, parts](unsigned k) { fn(n * k / parts, n * (k + 1) / parts); };
+        Job job;
+        job.body = &body; job.parts = parts;
         {
             std::lock_guard<std::mutex> g(m_);
-            job_ = [&body](unsigned k) { body(k); };
-            parts_ = parts; next_ = 0; done_ = 0; ++epoch_;
+            open_.push_back(&job);
         }
-        cv_work_.notify_all();
-        work();   // the caller takes parts too
+        for (unsigned k = 1; k < parts; ++k) cv_work_.notify_one();
+        // the caller works on ITS job only (another caller's job may be long: this one must not wait for it)
         std::unique_lock<std::mutex> g(m_);
-        cv_done_.wait(g, [&] { return done_ == parts_; });
-        job_ = nullptr;
+        while (job.next < job.parts) {
+            const unsigned k = job.next++;
+            if (job.next == job.parts) close(&job);
+            g.unlock();
+            body(k);
+            g.lock();
+            ++job.done;
+        }
+        job.cv.wait(g, [&] { return job.done == job.parts; });
     }
-    static constexpr size_t kWaitFrom = 32768;   // elements from which a caller that finds the pool busy waits for it
+    unsigned workers() const { return (unsigned)workers_.size(); }
 private:
+    struct Job {
+        std::function<void(unsigned)>* body = nullptr;
+        unsigned parts = 0, next = 0, done = 0;
+        std::condition_variable cv;   // signalled under m_ when done == parts (the job lives on its caller's stack)
+    };
     HostPool()
     {
-        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        try { for (unsigned k = 1; k < hw; k++) workers_.emplace_back([this] { loop(); }); } catch (...) {}   // fewer threads, or none: still correct
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nw = std::min(kMaxWorkers, hw - 1);
+        try { for (unsigned k = 0; k < nw; k++) workers_.emplace_back([this] { loop(); }); } catch (...) {}   // fewer threads, or none: still correct
     }
     ~HostPool()
     {
@@ -55,42 +69,29 @@ private:
         cv_work_.notify_all();
         for (auto& t : workers_) if (t.joinable()) t.join();
     }
-    void work()
-    {
-        for (;;) {
-            unsigned k;
-            std::function<void(unsigned)> job;
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (!job_ || next_ >= parts_) return;
-                k = next_++;
-                job = job_;
-            }
-            job(k);
-            bool last;
-            { std::lock_guard<std::mutex> g(m_); last = ++done_ == parts_; }
-            if (last) cv_done_.notify_all();
-        }
-    }
+    void close(Job* j) { open_.erase(std::find(open_.begin(), open_.end(), j)); }   // (m_ held) every part is taken: off the list
     void loop()
     {
-        uint64_t seen = 0;
+        std::unique_lock<std::mutex> g(m_);
         for (;;) {
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_work_.wait(g, [&] { return stop_ || epoch_ != seen; });
-                if (stop_) return;
-                seen = epoch_;
-            }
-            work();
+            cv_work_.wait(g, [&] { return stop_ || !open_.empty(); });
+            if (stop_) return;
+            // jobs in turn: the front job gives a part and goes to the back, so concurrent loops share the workers evenly
+            Job* const j = open_.front();
+            const unsigned k = j->next++;
+            open_.pop_front();
+            if (j->next < j->parts) open_.push_back(j);
+            std::function<void(unsigned)>* const body = j->body;
+            g.unlock();
+            (*body)(k);
+            g.lock();
+            if (++j->done == j->parts) j->cv.notify_all();   // under m_: the caller cannot leave run() (and destroy the job) before we let go
         }
     }
-    std::mutex use_, m_;
-    std::condition_variable cv_work_, cv_done_;
+    std::mutex m_;
+    std::condition_variable cv_work_;
     std::vector<std::thread> workers_;
-    std::function<void(unsigned)> job_;
-    unsigned parts_ = 0, next_ = 0, done_ = 0;
-    uint64_t epoch_ = 0;
+    std::deque<Job*> open_;   // jobs with parts left to hand out
     bool stop_ = false;
 };
 

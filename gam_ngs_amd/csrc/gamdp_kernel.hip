@@ -1115,6 +1115,7 @@ const char* kernel_name(int kid)
     case K_GEN_C5:     return "k_align<5,-1,true>";
     case K_GEN_C9:     return "k_align<9,-1,true>";
     case K_GEN_C17:    return "k_align<17,-1,true>";
+    case K_WIDE:       return "k_align_w";
     default:           return "?";
     }
 }
@@ -1126,7 +1127,7 @@ bool kernel_n_aware(int kid)
     }
 }
 
-int kernel_waves_per_cu(int kid) { return 4 * ((kid == K_P17_CE4 || kid == K_O19_CE15) ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
+int kernel_waves_per_cu(int kid) { return kid == K_WIDE ? WIDE_WORKGROUPS_PER_CU : 4 * ((kid == K_P17_CE4 || kid == K_O19_CE15) ? GAMDP_PAIR_WAVES_PER_SIMD : GAMDP_WAVES_PER_SIMD); }
 int kernel_tasks_per_wave(int kid) { return (kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? QT : (kid == K_P17_CE4 ? 2 : (kid == K_O19_CE15 ? 2 * QT : 1)); }
 // words per block of the direction image: lane major (LANE_WORDS per lane) in the direction-free kernels
 static_assert(DIRFREE_OK<4, 17, false> && DIRFREE_OK<4, 17, true> && DIRFREE_OK<15, 19, false> && DIRFREE_OK<15, 19, true> &&
@@ -1139,6 +1140,7 @@ int kernel_dir_block_words(int kid)
     case K_Q19_CE15: case K_Q19_CE15_N: case K_O19_CE15: return IMG_WORDS<19, true>;
     case K_GEN_C17: return IMG_WORDS<17, true>;
     case K_GEN_C9: return IMG_WORDS<9, true>;
+    case K_WIDE: return 1;   // (no direction image: the slot holds the band matrix itself, sized by the host)
     default: return kernel_cols(kid) * 64;
     }
 }
@@ -1192,6 +1194,7 @@ unsigned kernel_static_lds(int kid)
 {
     static unsigned cache[K_COUNT] = {0};
     if (kid < 0 || kid >= K_COUNT) return 0;
+    if (kid == K_WIDE) return wide_static_lds();
     if (cache[kid] == 0) {
         hipFuncAttributes a;
         const void* f = kernel_ptr(kid);
@@ -1203,6 +1206,7 @@ unsigned kernel_static_lds(int kid)
 // dyn_lds: unused dynamic LDS that only limits how many workgroups share a CU (see the launch planner in gamdp_host.cpp)
 int launch_align(int kid, const LaunchParams& p, unsigned n_slots, unsigned dyn_lds, void* stream)
 {
+    if (kid == K_WIDE) return launch_wide(p, n_slots, stream);
     const void* f = kernel_ptr(kid);
     if (!f) return (int)hipErrorInvalidValue;
     LaunchParams lp = p;

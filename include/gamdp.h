@@ -40,7 +40,7 @@ extern "C" {
 #define GAMDP_EINVAL  (-1)  /* bad argument                                        */
 #define GAMDP_ENODEV  (-2)  /* no usable GPU / HIP runtime failure at context setup */
 #define GAMDP_ENOMEM  (-3)  /* host or device allocation failed                    */
-#define GAMDP_ENOTSUP (-4)  /* band wider than the compiled kernels support        */
+#define GAMDP_ENOTSUP (-4)  /* band wider than GAMDP_MAX_BAND                          */
 #define GAMDP_EHIP    (-5)  /* a HIP call failed at run time (see gamdp_last_error) */
 
 /* per-task status, mirrors the reference's observable outcomes */
@@ -60,7 +60,12 @@ extern "C" {
 #define GAMDP_OP_MISMATCH 3
 
 #define GAMDP_DEFAULT_BAND 150   /* DEFAULT_BAND_SIZE, banded_smith_waterman.hpp:38 */
-#define GAMDP_MAX_BAND 543       /* widest band the compiled kernels cover (2*band+1 <= 64*17) */
+/* The reference takes any band (banded_smith_waterman.hpp:66).  So does this library, up to GAMDP_MAX_BAND = 2^20 (beyond it the
+ * reference's own index arithmetic is untested and the oracle declines): bands up to GAMDP_MAX_TUNED_BAND run on the systolic
+ * kernels (2*band+1 <= 64 lanes x 17 columns), wider ones on a correct-at-any-speed kernel that keeps the whole band matrix
+ * (x_size * (2*band+1) int32) in the scratch arena -- a call whose matrix does not fit the arena fails with GAMDP_ENOMEM. */
+#define GAMDP_MAX_BAND 1048576
+#define GAMDP_MAX_TUNED_BAND 543
 
 typedef struct gamdp_ctx gamdp_ctx;
 typedef struct gamdp_seqset gamdp_seqset;

@@ -335,11 +335,52 @@ def test_n_by_contig_in_a_fresh_process():
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2000:]
 
 
-def test_band_too_wide_is_refused_loudly():
+def test_the_limits_that_remain_for_wide_bands():
+    """The reference takes any band (banded_smith_waterman.hpp:66); since round 6 so does the library (k_align_w for bands > 543,
+    gamdp_wide.hip).  What is left (include/gamdp.h): a band beyond GAMDP_MAX_BAND = 2^20 is refused (GAMDP_ENOTSUP), and a
+    wide-band call whose matrix does not fit the scratch arena fails with GAMDP_ENOMEM -- loudly, both."""
     c = ctx()
     sset = gam.SequenceSet(c, [b"ACGT" * 10, b"ACGT" * 10])
-    with pytest.raises(gam.GamdpError):
-        gam.BandedSmithWaterman(c, 600).find_alignment(sset.contig(0), 0, 39, sset.contig(1), 0, 39)
+    with pytest.raises(gam.GamdpError, match="GAMDP_MAX_BAND"):
+        gam.BandedSmithWaterman(c, (1 << 20) + 1).find_alignment(sset.contig(0), 0, 39, sset.contig(1), 0, 39)
+    # the widest band the library takes, and a band no lane geometry divides, on tiny inputs: bit-exact
+    cases = [dict(a=b"ACGTTGCA" * 5, b=b"ACGTTGCA" * 5, band=1 << 20, begin_a=0, end_a=39, begin_b=0, end_b=4, fs=False, fe=False),
+             dict(a=b"ACGTTGCAAT" * 30, b=b"GTTGCAATAC" * 30, band=100003, begin_a=7, end_a=299, begin_b=2, end_b=290, fs=False, fe=True)]
+    for cs, r in zip(cases, run_cases(cases)):
+        o, ops = oracle_for(cs)
+        assert o.status == O.OK and r.key() == o.key() and r.ops == ops
+    assert {x["kernel"] for x in c.launch_info()} == {"k_align_w"}
+    rng = random.Random(77)
+    a, b = _cases.related_pair(rng, 9000)
+    big = gam.SequenceSet(c, [a.encode(), b.encode()])
+    try:
+        c.set_arena_bytes(64 << 20)   # 9 000 rows x 4 097 columns x 4 B = 147 MB
+        with pytest.raises(gam.GamdpError, match="arena"):
+            gam.BandedSmithWaterman(c, 2048).find_alignment(big.contig(0), 0, len(a) - 1, big.contig(1), 0, len(b) - 1)
+    finally:
+        c.set_arena_bytes(0)
+    r = gam.BandedSmithWaterman(c, 2048).find_alignment(big.contig(0), 0, len(a) - 1, big.contig(1), 0, len(b) - 1)
+    o, _ = oracle_for(dict(a=a.encode(), b=b.encode(), band=2048, begin_a=0, end_a=len(a) - 1, begin_b=0, end_b=len(b) - 1, fs=False, fe=False), False)
+    assert r.key() == o.key() and o.status == O.OK
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_cases_vs_oracle_wide_bands(seed):
+    """test_random_cases_vs_oracle for bands beyond the systolic kernels (k_align_w): every status, force flags, N, ragged windows."""
+    cases = _cases.cases(9100 + seed, 300, max_len=400 if seed == 0 else 1500, bands=(544, 600, 1000, 2048))
+    for want_ops in (True, False):
+        res = run_cases(cases, want_ops=want_ops)
+        bad = []
+        n_ok = 0
+        for cs, r in zip(cases, res):
+            o, ops = oracle_for(cs, want_ops)
+            if o.status == O.INVALID:
+                continue
+            if r.key() != o.key() or (want_ops and r.ops != ops):
+                bad.append((cs, r.key(), o.key()))
+            n_ok += o.status == O.OK
+        assert not bad, bad[:3]
+        assert n_ok > 100
 
 
 def test_empty_batch_and_degenerate_sequences():
@@ -663,7 +704,7 @@ def test_window_cases_on_long_pairs(seed):
         c.set_arena_bytes(0)
 
 
-@pytest.mark.parametrize("band", [129, 160, 200, 256, 287, 288, 300, 400, 500, 543])
+@pytest.mark.parametrize("band", [129, 160, 200, 256, 287, 288, 300, 400, 500, 543, 600, 1000, 2048])
 def test_generic_bands_on_long_pairs(band):
     """Bands other than the two tuned ones: the generic kernels with 9 (bands 160 - 287) and 17 columns per lane (288 - 543) fill their fast
     blocks without directions since round 5 (band 129: 5 columns per lane, a direction per cell as before) -- a RUNTIME (lane, column) for the band's last column in the direction-free cell
@@ -684,9 +725,44 @@ def test_generic_bands_on_long_pairs(band):
             assert (not want_ops) or r.ops == ops, (band, k)
     assert n >= 60
     info = ctx().launch_info()
+    if band > 543:   # round 6: no lane geometry covers it -- the correct-at-any-speed kernel (gamdp_wide.hip), same cases
+        assert {r["kernel"] for r in info} == {"k_align_w"}, info
+        return
     cols = next(c for c in (2, 3, 5, 9, 17) if 2 * band + 1 <= c * 64)     # gamdp_host.cpp pick_kernel
     assert {r["kernel"] for r in info} == {"k_align<%d,-1,true>" % cols}, info
     assert sum(r["units_dirfree"] for r in info) >= (20 if cols >= 9 else 0), info      # the long ones did run a direction-free range
+
+
+def _band_with_edge_column(C, k):
+    """a band of the C-columns-per-lane generic kernel whose last column sits at in-lane position k = (2 * band) % C"""
+    lo, hi = {9: (160, 287), 17: (288, 543)}[C]
+    return next(b for b in range(lo + 11, hi + 1) if (2 * b) % C == k)
+
+
+@pytest.mark.parametrize("C", [9, 17])
+def test_every_edge_column_instance_of_the_generic_direction_free_blocks(C):
+    """df_range (gamdp_kernel.hip) sends the direction-free blocks of a generic band to the instance of the tuned fast range
+    whose COMPILE-TIME edge column is the band's, chosen by (Y - 1) % C: 8 instances for 9 columns per lane, 16 for 17, each in END and
+    non-END form (edge column C - 1 takes the runtime path).  One band per residue, paths from one band edge to the other on pairs long
+    enough for a direction-free range, edit strings included."""
+    seen = set()
+    for k in range(C):
+        band = _band_with_edge_column(C, k)
+        assert (2 * band) % C == k
+        cases = _cases.displaced_path_cases(band, n=2300)[::2] + _cases.window_cases(band, band, count=6)
+        for want_ops in (False, True):
+            res = run_cases(cases, want_ops=want_ops)
+            for q, (cs, r) in enumerate(zip(cases, res)):
+                o, ops = oracle_for(cs, want_ops)
+                if o.status == O.INVALID:
+                    continue
+                assert r.key() == o.key(), (C, k, band, q, r.key(), o.key())
+                assert (not want_ops) or r.ops == ops, (C, k, band, q)
+        info = ctx().launch_info()
+        assert {r["kernel"] for r in info} == {"k_align<%d,-1,true>" % C}, (band, info)
+        assert sum(r["units_dirfree"] for r in info) >= 8, (band, info)
+        seen.add(k)
+    assert seen == set(range(C))
 
 
 def test_paths_in_every_strip():
