@@ -124,22 +124,32 @@ def cpu_baseline(length, band, pair_ids):
     return rec, keys
 
 
+CPU_THREADS_MEASURED = 16   # see cpu_threads()
+
+
 def cpu_threads(length, band):
-    """Threads of the CPU baseline: every hardware thread of the box (T = hardware_concurrency()), fewer only
-    where the reference's own memory appetite forces it -- it allocates the whole band matrix per in-flight pair (8 B per
-    cell: 410 MB for a 50 kb pair at band 512), so the pool is capped at half of the box's available memory.  Returns
-    (threads, None | the reason for a cap) -- the reason is printed next to `cores` in the line."""
+    """Threads of the CPU baseline and, when that is fewer than the box has, why.  SURVEY.md 8d asks for T = hardware_concurrency();
+    measured on the GPU box (256 hardware threads, round 6, gpurun_out/r6_bench1.json): the reference's find_alignment on 512 of the
+    50 kb x band-512 pairs runs at 0.124 GCUPS on 256 threads (211.7 s) against 1.9 - 2.0 GCUPS on 16 (13 s) -- every in-flight pair
+    zero-fills a 410 MB matrix of its own (banded_smith_waterman.cc:102-107) and 256 of them fight over page faults and memory
+    bandwidth.  The baseline is meant to show the reference at its best on this box, so the pool stays at 16 (BENCH_CPU_THREADS=n
+    overrides), never more than half of the available memory allows; the cap and its reason are printed next to `cores`."""
     hw = os.cpu_count() or 1
+    want = int(os.environ.get("BENCH_CPU_THREADS", "0")) or min(hw, CPU_THREADS_MEASURED)
     per_pair = 8 * (length + 1) * (2 * band + 1) + (64 << 20)
     try:
         avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     except (ValueError, OSError):
         avail = 0
-    fit = max(1, int(avail * 0.5 // per_pair)) if avail else hw
-    if fit < hw:
-        return fit, ("%d of %d hardware threads: the reference holds a %d MB matrix per in-flight pair and half of the "
-                     "available memory (%.0f GB) fits %d" % (fit, hw, per_pair >> 20, avail / 2**30, fit))
-    return hw, None
+    fit = max(1, int(avail * 0.5 // per_pair)) if avail else want
+    threads = max(1, min(want, fit))
+    if threads >= hw:
+        return threads, None
+    if threads < want:
+        return threads, "%d of %d hardware threads: the reference holds a %d MB matrix per in-flight pair, half of the available memory fits %d" % (
+            threads, hw, per_pair >> 20, fit)
+    return threads, ("%d of %d hardware threads: the reference does not scale on this workload -- measured on this pool's 256-thread box: "
+                     "0.124 GCUPS on 256 threads against 1.9 - 2.0 on 16 (a %d MB zero-filled matrix per in-flight pair)" % (threads, hw, per_pair >> 20))
 
 
 def launch_summary(ctx):

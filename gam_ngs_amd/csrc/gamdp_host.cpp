@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,7 @@
 #include "gamdp_dev.h"
 #include "gamdp_internal.h"
 #include "gamdp_hostpool.h"
+#include "gamdp_hostsort.h"
 
 namespace gamdp {
 
@@ -366,29 +368,6 @@ static void parallel_for(size_t n, F fn)
     HostPool::get().run(n, fn);
 }
 
-// ids (ascending on entry) -> stable order of decreasing key[id]; LSD radix sort, 3 passes of 11 bits (keys < 2^33)
-static void sort_by_key_desc(std::vector<u32>& ids, const std::vector<u64>& key)
-{
-    const size_t n = ids.size();
-    if (n < 2) return;
-    if (n < 4096) {
-        std::stable_sort(ids.begin(), ids.end(), [&](u32 x, u32 y) { return key[x] > key[y]; });
-        return;
-    }
-    u64 kmax = 0;
-    for (u32 i : ids) kmax = std::max(kmax, key[i]);
-    std::vector<u32> tmp(n);
-    std::vector<u32>*src = &ids, *dst = &tmp;
-    for (unsigned shift = 0; shift < 64 && (kmax >> shift) != 0; shift += 11) {
-        size_t count[2049] = {0};
-        for (u32 i : *src) count[2047 - ((key[i] >> shift) & 2047) + 1]++;   // inverted digit: descending order
-        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
-        for (u32 i : *src) (*dst)[count[2047 - ((key[i] >> shift) & 2047)]++] = i;
-        std::swap(src, dst);
-    }
-    if (src != &ids) ids.swap(tmp);
-}
-
 // Validation in the order of banded_smith_waterman.cc:90-132 on plain numbers.  Returns GAMDP_ST_OK when the task has
 // to run on the GPU (then *X_out = rows of the band matrix), otherwise the final status the reference's behaviour maps
 // to; *cells_out = x_size * y_size whenever the reference got as far as sizing its matrix.
@@ -477,13 +456,32 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             for (auto& p : need) if (p.first == s) { p.second.push_back(id); return; }
             need.push_back({s, {id}});
         };
-        for (size_t ti = 0; ti < n; ti++) {
-            const ITask& t = tasks[ti];
+        // (checked in parallel: a serial pass over 100 000 tasks is 0.2 ms in front of every launch; the first offender by index is reported)
+        std::atomic<size_t> bad_at{n};
+        std::atomic<bool> any_rc{false};
+        parallel_for(n, [&](size_t lo, size_t hi) {
+            bool rc_seen = false;
+            for (size_t ti = lo; ti < hi; ti++) {
+                const ITask& t = tasks[ti];
+                const bool bad = t.band > GAMDP_MAX_BAND || t.a_id >= t.sa->lens.size() || t.b_id >= t.sb->lens.size() ||
+                                 (t.a_rc && !t.sa->has_codes()) || (t.b_rc && !t.sb->has_codes());
+                if (bad) { size_t cur = bad_at.load(); while (ti < cur && !bad_at.compare_exchange_weak(cur, ti)) {} break; }
+                rc_seen |= t.a_rc || t.b_rc;
+            }
+            if (rc_seen) any_rc.store(true);
+        });
+        if (bad_at.load() < n) {
+            const ITask& t = tasks[bad_at.load()];
             if (t.band > GAMDP_MAX_BAND) { set_error("band " + std::to_string(t.band) + " exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
             if (t.a_id >= t.sa->lens.size() || t.b_id >= t.sb->lens.size()) { set_error("sequence id out of range"); return GAMDP_EINVAL; }
-            if ((t.a_rc && !t.sa->has_codes()) || (t.b_rc && !t.sb->has_codes())) { set_error("reverse complement requested on a packed-only (synthetic) sequence set"); return GAMDP_EINVAL; }
-            if (t.a_rc) add(t.sa, t.a_id);
-            if (t.b_rc) add(t.sb, t.b_id);
+            set_error("reverse complement requested on a packed-only (synthetic) sequence set"); return GAMDP_EINVAL;
+        }
+        if (any_rc.load()) {
+            for (size_t ti = 0; ti < n; ti++) {
+                const ITask& t = tasks[ti];
+                if (t.a_rc) add(t.sa, t.a_id);
+                if (t.b_rc) add(t.sb, t.b_id);
+            }
         }
         for (auto& p : need) { int rc_ = p.first->ensure_rc(p.second, this); if (rc_) return rc_; }
     }
@@ -492,34 +490,55 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                diag_count_mat = diag().count_mat;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    // GAMDP_DIAG_TIMING: where the host side of the call spends its time, phase by phase (ms since the call began)
+    std::vector<std::pair<const char*, double>> marks;
+    auto mark = [&](const char* what) { if (diag_timing) marks.push_back({what, since(t_begin)}); };
     // per-batch work arrays live in the context: a fresh 50 MB vector per call costs more in page faults than the
     // preparation itself
-    if (w_prep.size() < n) { w_prep.resize(n); w_status.resize(n); w_key.resize(n); }
+    if (w_prep.size() < n) { w_prep.resize(n); w_status.resize(n); w_key.resize(n); w_kid.resize(n); w_rows.resize(n); }
     std::vector<Prepared>& prep = w_prep;
     std::vector<int>& prep_status = w_status;
+    // what the serial steps below need of a task, side by side (round 6): its kernel (-1: settled by the pre-checks) and its rows --
+    // 5 bytes per task instead of a pass over the 120-byte descriptors (12 MB per 100 000 tasks, three times over: 1.1 ms of a
+    // driver-shaped batch's 4.3 ms in front of the launch)
+    std::vector<int8_t>& kidv = w_kid;
+    std::vector<u32>& rowsv = w_rows;
+    const u32 diag_flags = (diag_skip_tb ? (u32)TF_DIAG_SKIP_TRACEBACK : 0u) | (diag_no_dirfree ? (u32)TF_NO_DIRFREE : 0u) | (diag_count_mat ? (u32)TF_DIAG_COUNT_MAT : 0u);
+    const bool any_ops = ops && ops->ops_buf;
     // validation + descriptor of every task: independent per task, spread over host threads for big batches
-    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) prep_status[i] = prepare_task(tasks[i], prep[i]); });
+    parallel_for(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const int st = prep_status[i] = prepare_task(tasks[i], prep[i]);
+            w_key[i] = prep[i].cells;   // the planner's sort key (and the `cells` of the result)
+            if (st != GAMDP_ST_OK) {
+                kidv[i] = -1; rowsv[i] = 0;
+                std::memset(&out[i], 0, sizeof(out[i]));
+                out[i].status = (uint8_t)st;
+                out[i].cells = prep[i].cells;  // 0 unless the reference got as far as sizing its matrix
+                continue;
+            }
+            prep[i].dt.res_idx = (u32)i;
+            prep[i].dt.flags |= diag_flags;
+            kidv[i] = (int8_t)prep[i].kid; rowsv[i] = (u32)prep[i].dt.X;
+        }
+    });
+    mark("pre-checks");
     std::vector<std::vector<u32>> groups(K_COUNT);
     u64 ops_total = 0;
-    for (size_t i = 0; i < n; i++) {
-        const int st = prep_status[i];
-        if (st != GAMDP_ST_OK) {
-            std::memset(&out[i], 0, sizeof(out[i]));
-            out[i].status = (uint8_t)st;
-            out[i].cells = prep[i].cells;  // 0 unless the reference got as far as sizing its matrix
-            continue;
-        }
-        prep[i].dt.res_idx = (u32)i;
-        if (diag_skip_tb) prep[i].dt.flags |= TF_DIAG_SKIP_TRACEBACK;
-        if (diag_no_dirfree) prep[i].dt.flags |= TF_NO_DIRFREE;
-        if (diag_count_mat) prep[i].dt.flags |= TF_DIAG_COUNT_MAT;
-        if (ops && ops->ops_buf && ops->ops_cap[i] > 0) {
+    if (any_ops) {   // edit strings: where each task's go (in task order)
+        for (size_t i = 0; i < n; i++) {
+            if (kidv[i] < 0 || ops->ops_cap[i] == 0) continue;
             prep[i].dt.flags |= TF_WANT_OPS;
             prep[i].dt.ops_off = ops_total;
             prep[i].dt.ops_cap = ops->ops_cap[i];
             ops_total += ops->ops_cap[i];
         }
-        groups[prep[i].kid].push_back((u32)i);
+    }
+    {
+        size_t per_kid[K_COUNT] = {0};
+        for (size_t i = 0; i < n; i++) if (kidv[i] >= 0) per_kid[kidv[i]]++;
+        for (int k = 0; k < K_COUNT; k++) groups[k].reserve(per_kid[k]);
+        for (size_t i = 0; i < n; i++) if (kidv[i] >= 0) groups[kidv[i]].push_back((u32)i);
     }
 
     // Small band-150 batches (merge-block rounds): one launch instead of two.  The launches of a batch run one after the
@@ -531,7 +550,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         static const bool keep_split = std::getenv("GAMDP_NO_MERGE_N") != nullptr || std::getenv("GAMDP_QUAD_MIN") != nullptr;
         auto &f = groups[K_C5_CE0], &a = groups[K_C5_CE0_N];
         if (!keep_split && !f.empty() && !a.empty() && f.size() + a.size() <= (size_t)n_cu * (size_t)kernel_waves_per_cu(K_C5_CE0_N)) {
-            for (u32 i : f) prep[i].kid = K_C5_CE0_N;
+            for (u32 i : f) { prep[i].kid = K_C5_CE0_N; kidv[i] = (int8_t)K_C5_CE0_N; }
             std::vector<u32> all(f.size() + a.size());
             std::merge(f.begin(), f.end(), a.begin(), a.end(), all.begin());   // both ascending: stays ascending
             a.swap(all);
@@ -554,7 +573,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             // ... and long enough: below ~8 k rows the top / end blocks and the one-after-the-other walks of a
             // wavefront eat what the fill gains (measured: 400 000 x 2 kb pairs 15 % slower, 5 kb equal, 20 kb 8 % faster)
             u64 rows = 0;
-            for (u32 i : g) rows += (u64)prep[i].dt.X;
+            for (u32 i : g) rows += (u64)rowsv[i];
             // without N and with enough tasks to fill the chip eight at a time: two quads per wavefront, packed f16 (round 3: from
             // ~4 k rows on: 400 000 x 5 kb pairs measured 5 % faster than one task per wavefront, 9 % faster than four)
             // ... and, for long contigs, from 6 144 tasks on: more than the one-task kernel holds in one round (5 120), and a
@@ -577,13 +596,17 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
             const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
             const u64 C = (u64)kernel_cols(to);
-            for (u32 i : g) {
-                const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
-                prep[i].kid = to;
-                // (+ 3 blocks: the packed range of a wavefront ends behind its longest task, rounded up to a group, and a strip of the
-                // last group writes the direction words of the whole group -- run_octo)
-                prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1 + 3) * (u64)kernel_dir_block_words(to);
-            }
+            const u64 dbw = (u64)kernel_dir_block_words(to);
+            parallel_for(g.size(), [&](size_t lo, size_t hi) {
+                for (size_t k = lo; k < hi; k++) {
+                    const u32 i = g[k];
+                    const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
+                    prep[i].kid = to;
+                    // (+ 3 blocks: the packed range of a wavefront ends behind its longest task, rounded up to a group, and a strip of the
+                    // last group writes the direction words of the whole group -- run_octo)
+                    prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1 + 3) * dbw;
+                }
+            });
             groups[to] = std::move(g);
             g.clear();
         }
@@ -596,13 +619,15 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         static const bool no_pair = std::getenv("GAMDP_NO_PAIR") != nullptr;
         auto& g = groups[K_C17_CE4];
         if (!no_pair && !diag_no_dirfree && g.size() >= 2) {
-            for (u32 i : g) { prep[i].kid = K_P17_CE4; prep[i].dir_words += 3ull * (u64)kernel_dir_block_words(K_P17_CE4); }   // same C and LE; + 3 blocks as for the eight-task kernel above
+            const u64 add3 = 3ull * (u64)kernel_dir_block_words(K_P17_CE4);
+            parallel_for(g.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) { const u32 i = g[k]; prep[i].kid = K_P17_CE4; prep[i].dir_words += add3; } });   // same C and LE; + 3 blocks as for the eight-task kernel above
             groups[K_P17_CE4] = std::move(g);
             g.clear();
         }
     }
 
     const double ms_prep = since(t_begin);
+    mark("groups");
     int rc_ = grow(this, d_results, cap_results, n + 1);  // + one dump slot for the padding tasks of the 4-task kernels
     if (rc_) return rc_;
     if (ops_total) { rc_ = grow(this, d_ops, cap_ops, ops_total); if (rc_) return rc_; }
@@ -613,8 +638,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
 
     u64 n_host_tasks = 0;
     std::vector<u64>& cells_key = w_key;
-    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cells_key[i] = prep[i].cells; });
-    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; };
+    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; u32 band_max; };
     std::vector<Launch> launches;
     std::vector<std::vector<u32>> launch_items;   // the tasks of every launch, in launch order (staged once the plan is complete)
     // (Measured and dropped: handing the leftover of a multi-task group -- less than one round -- to a finer-grained kernel
@@ -635,9 +659,14 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             work.pop_back();
             u32 maxband = 0;
             u64 maxdir = 0;
-            for (u32 i : cur) {
-                maxband = std::max<u32>(maxband, (u32)prep[i].dt.band);
-                maxdir = std::max(maxdir, prep[i].dir_words);
+            {   // (a reduction over the descriptors in sorted -- i.e. random -- order: in parallel for big launches)
+                std::mutex red;
+                parallel_for(cur.size(), [&](size_t lo, size_t hi) {
+                    u32 mb = 0; u64 md = 0;
+                    for (size_t k = lo; k < hi; k++) { const u32 i = cur[k]; mb = std::max<u32>(mb, (u32)prep[i].dt.band); md = std::max(md, prep[i].dir_words); }
+                    std::lock_guard<std::mutex> gd(red);
+                    maxband = std::max(maxband, mb); maxdir = std::max(maxdir, md);
+                });
             }
             const u32 ypad = ((2 * maxband + 2 + 63) / 64) * 64;
             const u64 dirw = ((maxdir + 63) / 64) * 64;
@@ -668,7 +697,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             Launch L;
             const size_t padded = (cur.size() + tpw - 1) / tpw * tpw;
             L.kid = kid; L.first = (u32)n_host_tasks; L.count = (u32)padded;
-            L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad;
+            L.slot_words = slotw; L.dir_words = dirw; L.ypad = ypad; L.band_max = maxband;
             // (Measured and dropped: equalising the rounds of a launch -- 6 250 workgroups as 2 x 3 125 instead of 4 096 +
             // 2 154 -- and forcing an even spread over the CUs with unused dynamic LDS changed nothing: the hardware
             // dispatcher already spreads workgroups evenly, and what a short launch loses is per-SIMD occupancy.)
@@ -681,6 +710,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             launches.push_back(L);
         }
     }
+    mark("sort+plan");
     // Staging: the padded task list of all launches (the last wavefront of a multi-task launch is filled up with copies of
     // its last task that write to the dump slot), sized from the finished plan -- however many launches the peeling made.
     rc_ = grow(this, d_tasks, cap_tasks, n_host_tasks + 1);
@@ -708,6 +738,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         size_t k = cur.size();
         for (; k < L.count; k++) pad(k, dst[cur.size() - 1]);
     }
+    mark("staging");
     if (!launches.empty()) {
         u64 need_scratch = 0;
         for (auto& L : launches) need_scratch = std::max(need_scratch, L.slot_words * L.n_slots);
@@ -744,6 +775,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         }
         u32* const d_stats = d_cursor + cap_cursor;
         const double ms_plan = since(t_begin) - ms_prep;
+        mark("buffers");
         const auto t_gpu = std::chrono::steady_clock::now();
         HIPCHK(this, hipMemcpyAsync(d_tasks, h_tasks, n_host_tasks * sizeof(DevTask), hipMemcpyHostToDevice, stream));
         HIPCHK(this, hipMemsetAsync(d_cursor, 0, (size_t)cap_cursor * (1 + LS_COUNT) * sizeof(u32), stream));
@@ -795,14 +827,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         if (ops_total) HIPCHK(this, hipMemcpyAsync(hops.data(), d_ops, ops_total, hipMemcpyDeviceToHost, stream));
         std::vector<u32> hstats(log_launches ? launches.size() * LS_COUNT : 0);
         if (!hstats.empty()) HIPCHK(this, hipMemcpyAsync(hstats.data(), d_stats, hstats.size() * sizeof(u32), hipMemcpyDeviceToHost, stream));
+        mark("enqueued");
         HIPCHK(this, hipStreamSynchronize(stream));
+        mark("gpu done");
         const double ms_gpu = since(t_gpu);
-        if (diag_timing) {
-            // (ctx + the call's begin on the process's steady clock: tools/multi_host_overlap.py lays the host phases of several contexts side by side)
-            std::fprintf(stderr, "libgamdp align: %zu tasks, %zu launches: prepare %.2f ms, plan+stage %.2f ms, upload+kernels+download %.2f ms [ctx %p began %.3f]\n",
-                         n, launches.size(), ms_prep, ms_plan, ms_gpu, (void*)this,
-                         std::chrono::duration<double, std::milli>(t_begin.time_since_epoch()).count());
-        }
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
@@ -816,9 +844,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 r.tasks = (u32)launch_items[li].size();
                 r.units = L.count / r.tasks_per_wavefront;
                 r.slots = L.n_slots;
-                u32 bm = 0;
-                for (u32 i : launch_items[li]) bm = std::max<u32>(bm, (u32)prep[i].dt.band);
-                r.band_max = bm;
+                r.band_max = L.band_max;   // (from the planner's reduction: a pass over the launch's descriptors here was 1 ms per 100 000 tasks)
                 const u32* st = hstats.data() + li * LS_COUNT;
                 r.units_dirfree = st[LS_DIRFREE]; r.units_packed_top = st[LS_PACKED_TOP]; r.units_packed_top_mixed = st[LS_PACKED_TOP_MIXED];
                 r.strips = st[LS_STRIPS]; r.units_top_wanted = st[LS_TOP_WANTED];
@@ -833,24 +859,45 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             }
         }
         const auto t_fill = std::chrono::steady_clock::now();
-        parallel_for(n_host_tasks, [&](size_t lo, size_t hi) {
-            for (size_t q = lo; q < hi; q++) {
-                const DevTask& d = h_tasks[q];
-                const u32 i = d.res_idx;
-                if (i >= n) continue;  // padding of a 4-task launch
-                fill_result(hres[i], prep[i].cells, out[i]);
-                if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
-                    const u64 len = std::min<u64>(out[i].length, d.ops_cap);
-                    // the kernel wrote ops in traceback order: reverse into the caller's buffer
-                    uint8_t* dst = ops->ops_buf + ops->ops_off[i];
-                    const uint8_t* src = hops.data() + d.ops_off;
-                    if (out[i].length <= d.ops_cap) for (u64 k = 0; k < len; k++) dst[k] = src[len - 1 - k];
-                    else for (u64 k = 0; k < len; k++) dst[k] = 0xFF;  // truncated: not reconstructible
-                }
+        mark("events");
+        // results by task index (round 6: both arrays in order -- by launch position it was a random read and a random write per task)
+        parallel_for(n, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                if (kidv[i] < 0) continue;   // settled by the pre-checks
+                fill_result(hres[i], cells_key[i], out[i]);   // (cells_key[i] = prep[i].cells, 8 bytes apart instead of 120)
             }
         });
-        if (diag_timing) std::fprintf(stderr, "libgamdp align: results %.2f ms [ctx %p began %.3f]\n", since(t_fill), (void*)this,
-                                      std::chrono::duration<double, std::milli>(t_fill.time_since_epoch()).count());
+        if (ops_total) {
+            parallel_for(n_host_tasks, [&](size_t lo, size_t hi) {
+                for (size_t q = lo; q < hi; q++) {
+                    const DevTask& d = h_tasks[q];
+                    const u32 i = d.res_idx;
+                    if (i >= n) continue;  // padding of a multi-task launch
+                    if ((d.flags & TF_WANT_OPS) && out[i].status == GAMDP_ST_OK) {
+                        const u64 len = std::min<u64>(out[i].length, d.ops_cap);
+                        // the kernel wrote ops in traceback order: reverse into the caller's buffer
+                        uint8_t* dst = ops->ops_buf + ops->ops_off[i];
+                        const uint8_t* src = hops.data() + d.ops_off;
+                        if (out[i].length <= d.ops_cap) for (u64 k = 0; k < len; k++) dst[k] = src[len - 1 - k];
+                        else for (u64 k = 0; k < len; k++) dst[k] = 0xFF;  // truncated: not reconstructible
+                    }
+                }
+            });
+        }
+        if (diag_timing) {
+            mark("results");
+            // (every line at the END of the call: a write to stderr costs 0.2 - 2 ms on the GPU boxes, and in the middle of the call it
+            // was the largest item of the "results" phase it reported.  ctx + begin on the process's steady clock: tools/multi_host_overlap.py
+            // lays the host phases of several contexts side by side)
+            std::fprintf(stderr, "libgamdp align: %zu tasks, %zu launches: prepare %.2f ms, plan+stage %.2f ms, upload+kernels+download %.2f ms [ctx %p began %.3f]\n",
+                         n, launches.size(), ms_prep, ms_plan, ms_gpu, (void*)this,
+                         std::chrono::duration<double, std::milli>(t_begin.time_since_epoch()).count());
+            std::fprintf(stderr, "libgamdp align: results %.2f ms [ctx %p began %.3f]\n", marks.back().second - std::chrono::duration<double, std::milli>(t_fill - t_begin).count(), (void*)this,
+                         std::chrono::duration<double, std::milli>(t_fill.time_since_epoch()).count());
+            std::string line = "libgamdp align: phases (ms since the call began):";
+            for (auto& m : marks) { char b[64]; std::snprintf(b, sizeof b, " %s %.2f", m.first, m.second); line += b; }
+            std::fprintf(stderr, "%s; kernels %.2f ms\n", line.c_str(), [&] { double k = 0; for (auto& r : launch_log) k += r.kernel_ms; return k; }());
+        }
     }
     return 0;
 }
@@ -954,10 +1001,15 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     struct LogGuard { Ctx* c; ~LogGuard() { c->log_launches = false; for (Ctx* h : c->helpers) h->log_launches = false; } } log_guard{c};
     c->log_launches = true; c->log_piece = 0;
     return guarded(c, [&]() -> int {
+    const auto t_call = std::chrono::steady_clock::now();
     if (c->arena_budget(true) == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
+    const double ms_arena = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    double ms_conv = 0;   // (the calls taken over as ITasks: summed over the pieces)
+    struct CallTimer { std::chrono::steady_clock::time_point t0; size_t n; const double *arena, *conv; ~CallTimer() { if (diag().timing) std::fprintf(stderr, "libgamdp align_batch: %zu calls, %.2f ms in all (arena budget %.2f ms, calls taken over in %.2f ms)\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), *arena, *conv); } } call_timer{t_call, n, &ms_arena, &ms_conv};
     auto run = [&](Ctx* cc, size_t first, size_t cnt) -> int {
         if (cc->w_tasks.size() < cnt) cc->w_tasks.resize(cnt);
         std::vector<ITask>& it = cc->w_tasks;
+        const auto t_conv = std::chrono::steady_clock::now();
         parallel_for(cnt, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; i++) {
                 const gamdp_task& t = tasks[first + i];
@@ -965,6 +1017,7 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
                               t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
             }
         });
+        ms_conv += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_conv).count();   // (pieces on two threads: approximate)
         return cc->align(it.data(), cnt, out + first, nullptr);
     };
     // Very large batches of small calls (hundreds of thousands): validation, sorting, staging and result conversion of the

@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <deque>
 #include <functional>
 #include <mutex>
@@ -29,7 +30,7 @@ public:
     void run(size_t n, F& fn)
     {
         if (workers_.empty() || n < 2) { fn((size_t)0, n); return; }
-        const unsigned parts = (unsigned)std::min<size_t>(std::min<size_t>(kWidth, workers_.size() + 1), n);
+        const unsigned parts = (unsigned)std::min<size_t>(std::min<size_t>(width_, workers_.size() + 1), n);
         std::function<void(unsigned)> body = [&fn, n, parts](unsigned k) { fn(n * k / parts, n * (k + 1) / parts); };
         Job job;
         job.body = &body; job.parts = parts;
@@ -59,6 +60,7 @@ private:
     };
     HostPool()
     {
+        if (const char* e = std::getenv("GAMDP_HOST_WIDTH")) width_ = (unsigned)std::min(64, std::max(1, std::atoi(e)));   // (A/B; results do not depend on it)
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const unsigned nw = std::min(kMaxWorkers, hw - 1);
         try { for (unsigned k = 0; k < nw; k++) workers_.emplace_back([this] { loop(); }); } catch (...) {}   // fewer threads, or none: still correct
@@ -93,6 +95,7 @@ private:
     std::vector<std::thread> workers_;
     std::deque<Job*> open_;   // jobs with parts left to hand out
     bool stop_ = false;
+    unsigned width_ = kWidth;
 };
 
 }  // namespace gamdp

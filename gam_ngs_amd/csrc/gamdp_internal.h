@@ -139,6 +139,8 @@ struct Ctx {
     std::vector<Prepared> w_prep;
     std::vector<int> w_status;
     std::vector<u64> w_key;
+    std::vector<int8_t> w_kid;   // per task of the batch under way: its kernel (-1: settled by the pre-checks) ...
+    std::vector<u32> w_rows;     // ... and its rows
     std::vector<ITask> w_tasks;
 
     // buffers of the merge-block chain kernel (gamdp_l1.cpp), kept between calls

@@ -740,7 +740,7 @@ def _band_with_edge_column(C, k):
 
 
 @pytest.mark.parametrize("C", [9, 17])
-def test_every_edge_column_instance_of_the_generic_direction_free_blocks(C):
+def test_every_edge_column_instance_of_the_generic_df_ranges(C):
     """df_range (gamdp_kernel.hip) sends the direction-free blocks of a generic band to the instance of the tuned fast range
     whose COMPILE-TIME edge column is the band's, chosen by (Y - 1) % C: 8 instances for 9 columns per lane, 16 for 17, each in END and
     non-END form (edge column C - 1 takes the runtime path).  One band per residue, paths from one band edge to the other on pairs long
