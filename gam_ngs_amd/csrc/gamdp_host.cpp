@@ -303,6 +303,9 @@ Ctx::~Ctx()
     if (chain_stream) (void)hipStreamDestroy(chain_stream);
     if (h_tasks) (void)hipHostFree(h_tasks);
     if (h_results) (void)hipHostFree(h_results);
+    if (aux_done) (void)hipEventDestroy(aux_done);
+    if (aux_go) (void)hipEventDestroy(aux_go);
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -523,7 +526,11 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         }
     });
     mark("pre-checks");
-    std::vector<std::vector<u32>> groups(K_COUNT);
+    // (the per-kernel task lists and the sort's scratch keep their memory from call to call: freeing and re-allocating half a megabyte
+    // per call goes through mmap / munmap, and an munmap interrupts every thread of the host pool)
+    if (w_groups.size() != (size_t)K_COUNT) w_groups.resize(K_COUNT);
+    std::vector<std::vector<u32>>& groups = w_groups;
+    for (auto& gv : groups) gv.clear();
     u64 ops_total = 0;
     if (any_ops) {   // edit strings: where each task's go (in task order)
         for (size_t i = 0; i < n; i++) {
@@ -638,7 +645,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
 
     u64 n_host_tasks = 0;
     std::vector<u64>& cells_key = w_key;
-    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; u32 band_max; };
+    struct Launch { int kid; u32 first, count; u64 slot_words, dir_words; u32 ypad, n_slots, dyn_lds; u64 ckpt_off, bnd_off; u32 band_max; u64 scratch_off = 0; bool aux = false; };
     std::vector<Launch> launches;
     std::vector<std::vector<u32>> launch_items;   // the tasks of every launch, in launch order (staged once the plan is complete)
     // (Measured and dropped: handing the leftover of a multi-task group -- less than one round -- to a finer-grained kernel
@@ -649,11 +656,11 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         auto& g = groups[kid];
         if (g.empty()) continue;
         const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(kid);
-        sort_by_key_desc(g, cells_key);  // longest tasks first (LPT); ties keep the caller's order
+        sort_by_key_desc(g, cells_key, &w_sort_tmp, &w_sort_count);  // longest tasks first (LPT); ties keep the caller's order
         // One launch per group if slots sized for its largest direction matrix leave enough resident
         // waves; otherwise peel off the tasks with big matrices into their own launch and retry.
         std::vector<std::vector<u32>> work;
-        work.push_back(g);
+        work.push_back(g);   // (a copy: the group's own list keeps its memory for the next call)
         while (!work.empty()) {
             std::vector<u32> cur = std::move(work.back());
             work.pop_back();
@@ -710,6 +717,31 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             launches.push_back(L);
         }
     }
+    // A small launch beside a big one (round 6).  The launches of a call run one after the other and each lasts as long as its longest
+    // task: the ~900 calls of a driver-shaped batch whose windows hold N -- one one-task wavefront each, less than one per SIMD -- kept
+    // the chip for 1.35 ms before the eight-task launch of the other 99 000 began (11.6 % of the call's kernel time for 0.9 % of its
+    // calls).  Such a launch (one round of a one-task kernel, at most one wavefront per SIMD) now goes FIRST on a stream of its own, with
+    // its own piece of the task upload and its own region of the scratch arena, and the big launch (two rounds or more of a multi-task
+    // kernel) starts beside it: the small launch's wavefronts are the oldest on their SIMDs, which at equal priority get every issue
+    // slot they can use (kernel_common.inc), and three eight-task wavefronts per SIMD keep the vector pipe busy meanwhile.
+    // Results cannot depend on it: same kernels, same tasks, disjoint scratch.  GAMDP_NO_AUX_LAUNCH=1: one after the other (A/B).
+    {
+        static const bool no_aux = std::getenv("GAMDP_NO_AUX_LAUNCH") != nullptr;
+        int small = -1, big = -1;
+        for (size_t li = 0; li < launches.size(); li++) {
+            const Launch& L = launches[li];
+            const u64 tpw = (u64)kernel_tasks_per_wave(L.kid), units = L.count / tpw;
+            if (tpw == 1 && L.kid != K_WIDE && units <= (u64)L.n_slots && units <= 4ull * (u64)n_cu) { if (small < 0) small = (int)li; }
+            else if (tpw > 1 && units >= 2ull * L.n_slots) { if (big < 0) big = (int)li; }
+        }
+        if (!no_aux && !interval_sink && !defer_frees && small >= 0 && big >= 0 && launches.size() == 2) {
+            const u64 main_words = launches[big].slot_words * launches[big].n_slots, small_words = launches[small].slot_words * launches[small].n_slots;
+            if ((main_words + small_words) * sizeof(u32) <= arena_call) {   // (both regions inside this call's share of the arena)
+                launches[small].aux = true;
+                launches[small].scratch_off = main_words;
+            }
+        }
+    }
     mark("sort+plan");
     // Staging: the padded task list of all launches (the last wavefront of a multi-task launch is filled up with copies of
     // its last task that write to the dump slot), sized from the finished plan -- however many launches the peeling made.
@@ -741,7 +773,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     mark("staging");
     if (!launches.empty()) {
         u64 need_scratch = 0;
-        for (auto& L : launches) need_scratch = std::max(need_scratch, L.slot_words * L.n_slots);
+        for (auto& L : launches) need_scratch = std::max(need_scratch, L.scratch_off + L.slot_words * L.n_slots);
         if (need_scratch > cap_scratch) {
             if (d_scratch) { free_dev(d_scratch); d_scratch = nullptr; cap_scratch = 0; }
             // a round loop beside a chain launch: what a round holds depends on which chains have ended, so its needs move from
@@ -777,8 +809,25 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         const double ms_plan = since(t_begin) - ms_prep;
         mark("buffers");
         const auto t_gpu = std::chrono::steady_clock::now();
-        HIPCHK(this, hipMemcpyAsync(d_tasks, h_tasks, n_host_tasks * sizeof(DevTask), hipMemcpyHostToDevice, stream));
+        bool any_aux = false;
+        for (auto& L : launches) any_aux |= L.aux;
         HIPCHK(this, hipMemsetAsync(d_cursor, 0, (size_t)cap_cursor * (1 + LS_COUNT) * sizeof(u32), stream));
+        if (any_aux) {
+            if (!aux_stream) {
+                HIPCHK(this, hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+                HIPCHK(this, hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));
+                HIPCHK(this, hipEventCreateWithFlags(&aux_go, hipEventDisableTiming));
+            }
+            // the cursors are zero before anybody starts; the small launch's tasks go up on its own stream, ahead of the big upload
+            HIPCHK(this, hipEventRecord(aux_go, stream));
+            HIPCHK(this, hipStreamWaitEvent(aux_stream, aux_go, 0));
+            for (auto& L : launches)
+                if (L.aux) HIPCHK(this, hipMemcpyAsync(d_tasks + L.first, h_tasks + L.first, (size_t)L.count * sizeof(DevTask), hipMemcpyHostToDevice, aux_stream));
+            for (auto& L : launches)
+                if (!L.aux) HIPCHK(this, hipMemcpyAsync(d_tasks + L.first, h_tasks + L.first, (size_t)L.count * sizeof(DevTask), hipMemcpyHostToDevice, stream));
+        } else {
+            HIPCHK(this, hipMemcpyAsync(d_tasks, h_tasks, n_host_tasks * sizeof(DevTask), hipMemcpyHostToDevice, stream));
+        }
         while (events.size() < launches.size()) {
             hipEvent_t a, b;
             HIPCHK(this, hipEventCreate(&a));
@@ -790,7 +839,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             LaunchParams p;
             p.tasks = d_tasks + L.first; p.n_tasks = L.count; p.cursor = d_cursor + li;
             p.results = d_results; p.ops_buf = d_ops;
-            p.scratch = d_scratch; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
+            p.scratch = d_scratch + L.scratch_off; p.slot_words = L.slot_words; p.dir_words = L.dir_words; p.ypad = L.ypad;
             p.ckpt_off = L.ckpt_off; p.bnd_off = L.bnd_off;
             p.stats = d_stats + li * LS_COUNT;
             static const u64 side_rounds = [] { const char* e = std::getenv("GAMDP_SIDE_WALK_ROUNDS"); return e ? (u64)std::min(std::max(std::atol(e), 0L), 1000000L) : 2ull; }();
@@ -816,10 +865,15 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                 const u64 shaped = (L.kid == K_P17_CE4 ? 2ull : 1ull) * L.n_slots;
                 p.prio_from = units <= 2ull * L.n_slots ? 0u : (u32)(units - std::min<u64>(units, shaped));
             }
-            HIPCHK(this, hipEventRecord(events[li].first, stream));
-            const int e = launch_align(L.kid, p, L.n_slots, L.dyn_lds, stream);
+            hipStream_t const on = L.aux ? aux_stream : stream;
+            HIPCHK(this, hipEventRecord(events[li].first, on));
+            const int e = launch_align(L.kid, p, L.n_slots, L.dyn_lds, on);
             if (e != 0) { set_error(std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)e)); return GAMDP_EHIP; }
-            HIPCHK(this, hipEventRecord(events[li].second, stream));
+            HIPCHK(this, hipEventRecord(events[li].second, on));
+        }
+        if (any_aux) {   // the downloads below wait for both
+            HIPCHK(this, hipEventRecord(aux_done, aux_stream));
+            HIPCHK(this, hipStreamWaitEvent(stream, aux_done, 0));
         }
         DevResult* hres = h_results;
         HIPCHK(this, hipMemcpyAsync(hres, d_results, n * sizeof(DevResult), hipMemcpyDeviceToHost, stream));
@@ -831,9 +885,22 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         HIPCHK(this, hipStreamSynchronize(stream));
         mark("gpu done");
         const double ms_gpu = since(t_gpu);
+        float busy_hi = 0;   // (side-by-side launches: the end of the busy time so far, ms after the first launch began)
         for (size_t li = 0; li < launches.size(); li++) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) { kernel_ms += ms; kernel_launches++; }
+            if (hipEventElapsedTime(&ms, events[li].first, events[li].second) == hipSuccess) {
+                kernel_launches++;
+                if (!any_aux) kernel_ms += ms;
+                else {
+                    // launches that ran side by side: the context's kernel time is the time the GPU was busy with them (the union of
+                    // their intervals on the device's clock), not the sum of their durations
+                    float off = 0;
+                    if (li > 0 && hipEventElapsedTime(&off, events[0].first, events[li].first) != hipSuccess) off = busy_hi;
+                    const float lo = std::max(off, busy_hi), hi = off + ms;
+                    if (hi > lo) kernel_ms += hi - lo;
+                    busy_hi = std::max(busy_hi, hi);
+                }
+            }
             if (log_launches) {   // gamdp_ctx_launch_info: the planner's choice and what the device counted
                 const Launch& L = launches[li];
                 gamdp_launch_info r;
@@ -1063,7 +1130,11 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         const double units_per_piece = (double)n * (7.0 / 24.0) / (b150 ? 8.0 : 2.0);
         const bool one_length = (double)rows_max * (double)std::max<size_t>(1, cnt) <= 1.25 * (double)rows_sum;
         static const double min_rounds_env = [] { const char* e = std::getenv("GAMDP_CHUNK_MIN_ROUNDS"); return e ? std::min(std::max(std::atof(e), 0.0), 1000.0) : -1.0; }();
-        const double min_rounds = min_rounds_env >= 0 ? min_rounds_env : (one_length ? 0.5 : 2.5);
+        // (round 6, with the host side of a call at half its cost: calls of one length of >= 4 k rows stay whole below three rounds per piece --
+        // 131 072 x 5 kb 29.0 in pieces, 27.3 ms whole; 200 000 x 5 kb 43.8 / 41.6; 400 000 x 5 kb a tie; shorter calls keep half a round:
+        // 400 000 x 2 kb 40.3 / 42.9, 262 144 x 1 kb 18.7 / 22.7, 131 072 x 2 kb 14.6 / 15.7, 300 000 x 3 kb 41.5 / 42.1; tools/ab_chunks_r06.sh)
+        const double rows_avg = (double)rows_sum / (double)std::max<size_t>(1, cnt);
+        const double min_rounds = min_rounds_env >= 0 ? min_rounds_env : (one_length ? (rows_avg >= 4000.0 ? 3.0 : 0.5) : 2.5);
         if (units_per_piece < min_rounds * 16.0 * (double)c->n_cu) chunked = false;
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {

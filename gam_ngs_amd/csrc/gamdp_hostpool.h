@@ -26,11 +26,15 @@ public:
     static HostPool& get() { static HostPool p; return p; }
     static constexpr unsigned kWidth = 16;        // parts of one loop = threads a lone loop runs on
     static constexpr unsigned kMaxWorkers = 63;   // pool threads (beside the callers)
+    static constexpr unsigned kPartsPerThread = 4;
     template <class F>
     void run(size_t n, F& fn)
     {
         if (workers_.empty() || n < 2) { fn((size_t)0, n); return; }
-        const unsigned parts = (unsigned)std::min<size_t>(std::min<size_t>(width_, workers_.size() + 1), n);
+        // up to `width_` threads, four parts each: whoever is quick takes more of them (a loop used to wait for its slowest sixteenth --
+        // on a busy 256-thread host one descheduled worker doubled a phase of the call)
+        const unsigned threads = (unsigned)std::min<size_t>(std::min<size_t>(width_, workers_.size() + 1), n);
+        const unsigned parts = (unsigned)std::min<size_t>((size_t)threads * kPartsPerThread, n);
         std::function<void(unsigned)> body = [&fn, n, parts](unsigned k) { fn(n * k / parts, n * (k + 1) / parts); };
         Job job;
         job.body = &body; job.parts = parts;
@@ -38,7 +42,7 @@ public:
             std::lock_guard<std::mutex> g(m_);
             open_.push_back(&job);
         }
-        for (unsigned k = 1; k < parts; ++k) cv_work_.notify_one();
+        for (unsigned k = 1; k < threads; ++k) cv_work_.notify_one();
         // the caller works on ITS job only (another caller's job may be long: this one must not wait for it)
         std::unique_lock<std::mutex> g(m_);
         while (job.next < job.parts) {

@@ -13,7 +13,8 @@ namespace gamdp {
 // Big batches (round 6): every pass on the host pool -- P chunks of the array histogram their digits, one thread turns the P x BINS
 // counts into offsets (bins in descending digit order, chunks in order within a bin: stable), the chunks scatter.  Serially the three
 // passes over 100 000 ids were 1.2 ms in front of every launch of a driver-shaped batch.
-inline void sort_by_key_desc(std::vector<uint32_t>& ids, const std::vector<uint64_t>& key)
+// tmp_buf / count_buf: scratch the caller keeps between calls (nullptr: allocated here)
+inline void sort_by_key_desc(std::vector<uint32_t>& ids, const std::vector<uint64_t>& key, std::vector<uint32_t>* tmp_buf = nullptr, std::vector<size_t>* count_buf = nullptr)
 {
     const size_t n = ids.size();
     if (n < 2) return;
@@ -37,9 +38,13 @@ inline void sort_by_key_desc(std::vector<uint32_t>& ids, const std::vector<uint6
     while (nbits < 64 && (kmax >> nbits) != 0) nbits++;
     if (nbits == 0) return;   // every key 0: the order stays
     const int passes = (nbits + 11) / 12, BITS = (nbits + passes - 1) / passes, BINS = 1 << BITS;
-    std::vector<uint32_t> tmp(n);
+    std::vector<uint32_t> tmp_own;
+    std::vector<size_t> count_own;
+    std::vector<uint32_t>& tmp = tmp_buf ? *tmp_buf : tmp_own;
+    std::vector<size_t>& count = count_buf ? *count_buf : count_own;
+    tmp.resize(n);
+    if (count.size() < P * (size_t)BINS) count.resize(P * (size_t)BINS);
     std::vector<uint32_t>*src = &ids, *dst = &tmp;
-    std::vector<size_t> count(P * (size_t)BINS);
     for (unsigned shift = 0; shift < 64 && (kmax >> shift) != 0; shift += (unsigned)BITS) {
         const uint32_t* const sp = src->data();
         uint32_t* const dp = dst->data();

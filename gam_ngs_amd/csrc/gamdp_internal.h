@@ -93,6 +93,10 @@ struct Ctx {
     int n_cu = 0;
     u32 max_lds_per_wg = 65536;
     hipStream_t stream = nullptr;
+    // A batch call's small N-aware launch runs BESIDE its big throughput launch (Ctx::align): a second stream, created on first use,
+    // and the event that tells the first one when it is done
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_done = nullptr, aux_go = nullptr;
     std::string err;
     // Scratch-arena budget.  arena_limit is THE budget of this context's device as its owner sees it: what
     // gamdp_ctx_set_arena_bytes set, or -- while 0 -- 75 % of the free HBM at the first call.  It is never overwritten by
@@ -141,6 +145,8 @@ struct Ctx {
     std::vector<u64> w_key;
     std::vector<int8_t> w_kid;   // per task of the batch under way: its kernel (-1: settled by the pre-checks) ...
     std::vector<u32> w_rows;     // ... and its rows
+    std::vector<std::vector<u32>> w_groups;            // the tasks of the batch under way by kernel
+    std::vector<u32> w_sort_tmp; std::vector<size_t> w_sort_count;   // scratch of the planner's sort
     std::vector<ITask> w_tasks;
 
     // buffers of the merge-block chain kernel (gamdp_l1.cpp), kept between calls

@@ -119,3 +119,35 @@ def test_the_library_says_what_it_launched(n_calls, length, band, want):
     # results of equal calls are equal (and real)
     assert all(out[k].status == L.ST_OK and tuple(out[k].key()) == tuple(out[k % n_pairs].key()) for k in range(n_calls))
     sset.close()
+
+
+def test_small_n_aware_launch_beside_the_big_one():
+    """Round 6: a batch big enough for two rounds or more of the eight-task kernel whose few calls on contigs with N make one small
+    launch of the one-task N-aware kernel -- that launch runs BESIDE the big one (a second stream, its own region of the scratch arena;
+    Ctx::align in gamdp_host.cpp).  Every call of the small launch and a sample of the others against the oracle; and the same batch once
+    more in a child process with GAMDP_NO_AUX_LAUNCH=1 (one launch after the other): identical results, call for call."""
+    import hashlib, subprocess, sys
+    c = ctx()
+    seqs, calls = _mixed.mixed_batch(606, 8704, 8)   # 69 632 calls: 2.1 rounds of eight-task wavefronts
+    sset = gam.SequenceSet(c, seqs, ascii=False)
+    out = run_batch(c, sset, calls)
+    info = c.launch_info()
+    small = [r for r in info if r["tasks_per_wavefront"] == 1 and r["n_aware"]]
+    big = [r for r in info if r["kernel"] == "k_align_o<19,15>"]
+    assert len(info) == 2 and small and big and big[0]["rounds"] >= 2.0 and small[0]["rounds"] <= 1.0, info
+    has_n = [4 in s for s in seqs]
+    picked = [i for i, cl in enumerate(calls) if has_n[cl["a_id"]] or has_n[cl["b_id"]] or i % 97 == 0]
+    assert sum(1 for i in picked if has_n[calls[i]["a_id"]] or has_n[calls[i]["b_id"]]) >= small[0]["tasks"] > 100
+    want = oracle_keys(seqs, [calls[i] for i in picked])
+    bad = [i for i, w in zip(picked, want) if tuple(out[i].key()) != tuple(w)]
+    assert not bad, (len(bad), calls[bad[0]], out[bad[0]].key())
+    digest = hashlib.sha256(repr([tuple(out[i].key()) for i in range(len(calls))]).encode()).hexdigest()
+    sset.close()
+    if os.environ.get("GAMDP_MIXED_DIGEST_ONLY"):
+        print("DIGEST", digest)
+        return
+    env = dict(os.environ, GAMDP_NO_AUX_LAUNCH="1", GAMDP_MIXED_DIGEST_ONLY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", os.path.abspath(__file__), "-k", "small_n_aware_launch"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("DIGEST " + digest) in r.stdout, "results differ between the side-by-side launches and one after the other"

@@ -31,13 +31,16 @@ else:
 out = (L.Result * P)()
 ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None)   # warm-up
 ms0, n0 = ctx.kernel_time()
-best, tot, wall = 1e9, 0.0, 1e9
+best, tot, wall, walls = 1e9, 0.0, 1e9, []
 for rep in range(reps):
     t0 = time.perf_counter()
     assert ctx.lib.gamdp_align_batch(ctx.handle, sset.handle, sset.handle, tasks, P, out, None) == 0
-    wall = min(wall, (time.perf_counter() - t0) * 1e3)
+    walls.append((time.perf_counter() - t0) * 1e3)
+    wall = min(walls)
     ms1, n1 = ctx.kernel_time()
     best = min(best, ms1 - ms0); tot += ms1 - ms0; ms0 = ms1
 chk = sum(out[k].score for k in range(0, P, max(1, P // 4096)))
-names = "+".join(sorted({r["kernel"] for r in ctx.launch_info()}))
-print("%-22s %-28s kernels: best %8.2f ms  mean %8.2f ms   call: best %8.2f ms   (checksum %d)  %s" % (tag, shape, best, tot / reps, wall, chk, names))
+names = "+".join("%s %.2f ms" % (r["kernel"], r["kernel_ms"]) for r in ctx.launch_info())   # (of the last call)
+if os.environ.get("AB_WALLS"):
+    print("walls:", " ".join("%.1f" % w for w in walls))
+print("%-22s %-28s kernels: best %8.2f ms  mean %8.2f ms   call: best %8.2f median %8.2f mean %8.2f ms   (checksum %d)  %s" % (tag, shape, best, tot / reps, wall, sorted(walls)[len(walls) // 2], sum(walls) / len(walls), chk, names))
