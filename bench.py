@@ -333,7 +333,7 @@ def band150_record(ctx, m, length, steps=2, warmup=1, verify=128):
     return rec
 
 
-def mixed150_record(ctx, n_pairs=12500, calls_per_pair=8, steps=2, warmup=1, verify=256, seed=20261004):
+def mixed150_record(ctx, n_pairs=12500, calls_per_pair=8, steps=8, warmup=2, verify=256, seed=20261004):
     """A batch shaped like the live driver's calls (tests/_mixed.py: >= 100 000 band-150 calls on contigs of log-normal length 0.3 - 20 kb,
     random windows on both contigs, a tenth of the calls force_start / force_end tails, ~1 % of the contigs with runs of N), through
     the launch planner's own choice: GCUPS, the kernel mix as the library reports it, `verify` calls spread over the list compared
@@ -358,9 +358,12 @@ def mixed150_record(ctx, n_pairs=12500, calls_per_pair=8, steps=2, warmup=1, ver
     for _ in range(warmup):
         step()
     ctx.kernel_time(reset=True)
+    walls = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        t1 = time.perf_counter()
         step()
+        walls.append((time.perf_counter() - t1) * 1e3)
     dt = (time.perf_counter() - t0) / steps
     kernel_ms, launches = ctx.kernel_time()
     dominant, linfo = launch_summary(ctx)
@@ -372,7 +375,13 @@ def mixed150_record(ctx, n_pairs=12500, calls_per_pair=8, steps=2, warmup=1, ver
                        "%d force_start and %d force_end tail calls, %d calls that start inside the band's left triangle (tests/_mixed.py, seed %d)"
                        % (n, n_pairs, sum(c["fs"] for c in calls), sum(c["fe"] for c in calls), sum(1 for c in calls if c["begin_a"] < 135), seed),
            "calls": n, "mean_rows": sum(rows) / float(n), "gcups": cells / dt / 1e9, "steps": steps, "ms_per_step": dt * 1e3,
+           # (a 12 ms step on a 256-thread host: one step in ten or twenty is 4 - 6 ms late; gcups is over the mean of all steps)
+           "ms_per_step_median": sorted(walls)[len(walls) // 2], "ms_per_step_min": min(walls),
+           # kernel time = the time the GPU was busy with the call's launches: the small N-aware launch runs BESIDE the eight-task
+           # launch (gamdp_host.cpp: Ctx::align), so this is the union of their intervals, not the sum of launch_info's kernel_ms
            "kernel_ms_per_step": kernel_ms / steps, "launches_per_step": launches / float(steps), "kernel": dominant, "launch_info": linfo,
+           "roofline_frac_in_kernel": (cells * B_ALG / (kernel_ms / steps / 1e3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else None,
+           "roofline_frac_whole_step": cells * B_ALG / dt / 1e9 / HBM_PEAK_GBS,
            # of the eight-task wavefronts whose calls hold blocks with pos <= 0 cells behind the ramp, how many ran them packed
            "packed_top_share": (sum(r["units_packed_top"] for r in octo) / float(max(1, sum(r["units_top_wanted"] for r in octo)))) if units else None,
            "packed_top_units": sum(r["units_packed_top"] for r in octo), "octo_units": units,

@@ -142,7 +142,9 @@ int gamdp_ctx_set_arena_bytes(gamdp_ctx* ctx, uint64_t bytes);
 const char* gamdp_last_error(const gamdp_ctx* ctx);
 /* the hipStream_t the kernels run on, as an opaque pointer */
 void* gamdp_ctx_stream(gamdp_ctx* ctx);
-/* HIP-event timing of the DP kernel launches since the last reset: total ms and launch count */
+/* HIP-event timing of the DP kernel launches since the last reset: total ms and launch count.  Launches of one call that run side
+ * by side (a batch's small N-aware launch beside its big launch, each on a stream of its own) count with the time the GPU was busy
+ * with them -- the union of their intervals --, not with the sum of their durations. */
 int gamdp_ctx_kernel_time(gamdp_ctx* ctx, double* total_ms, uint64_t* launches, int reset);
 /* What the last gamdp_align_batch call on this context launched, in launch order (the pieces of a batch that went through in
  * pieces included): the library's own account of its launch planner's choices (which kernel instantiation a group of calls
@@ -163,7 +165,7 @@ typedef struct gamdp_launch_info {
     uint32_t piece;                  /* piece of a batch that went through in pieces (0 = the whole batch / its first piece) */
     uint32_t units_top_wanted;       /* units with a packed range whose calls hold blocks with pos <= 0 cells behind the ramp: what packed top blocks are for (device) */
     double rounds;                   /* units / slots */
-    double kernel_ms;                /* HIP events on the library's stream */
+    double kernel_ms;                /* HIP events around the launch, on the stream it ran on (this launch alone: side-by-side launches overlap) */
 } gamdp_launch_info;
 /* copies up to `cap` records to out (may be NULL when cap == 0); *n = how many launches the call made */
 int gamdp_ctx_launch_info(const gamdp_ctx* ctx, gamdp_launch_info* out, size_t cap, size_t* n);

@@ -20,9 +20,12 @@ def main():
     ap.add_argument("--per-seed", type=int, default=1000)
     ap.add_argument("--long", type=int, default=0, help="additional 3-9 kb related pairs (bands 64..512, N, windows, force flags)")
     ap.add_argument("--first-seed", type=int, default=0, help="continue a campaign: seeds first .. first + seeds - 1 (and another set of long pairs)")
+    ap.add_argument("--wide", action="store_true", help="bands beyond the systolic kernels only (k_align_w, round 6): 544 - 4 100")
     args = ap.parse_args()
     band_sets = [(0, 1, 2, 5, 8, 20, 150), (3, 31, 32, 63, 64, 95, 96), (127, 128, 150, 159, 160, 161, 287, 288, 289),
                  (512, 300, 543, 511, 513), (150,), (512,), (7, 40, 70, 100, 200, 256, 400)]
+    if args.wide:
+        band_sets = [(544, 545, 600, 1000), (2048, 777, 1500), (4100, 550, 3000)]
     total = ok = 0
     for seed in range(args.first_seed, args.first_seed + args.seeds):
         rng = random.Random(77000 + seed)
@@ -48,7 +51,7 @@ def main():
         for i in range(args.long):
             n = rng.randint(3000, 9000)
             a, b = _cases.related_pair(rng, n, n_frac=rng.choice([0.0, 0.0, 0.005, 0.02]), div=rng.choice([0.5, 1.0, 1.0, 2.0]))
-            band = rng.choice([150, 150, 512, 512, 64, 300])
+            band = rng.choice([600, 1000, 2048, 544]) if args.wide else rng.choice([150, 150, 512, 512, 64, 300])
             la, lb = len(a), len(b)
             if rng.random() < 0.5:
                 ba, bb = rng.randint(0, 600), rng.randint(0, 600)
