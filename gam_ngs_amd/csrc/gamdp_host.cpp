@@ -350,6 +350,27 @@ static int grow(Ctx* ctx, T*& ptr, u64& cap, u64 need)
 
 // ---- task validation (same order as banded_smith_waterman.cc:90-132) -------------------------------
 
+// words of a task's direction image in a slot of kernel `kid` (K_WIDE: the band matrix itself).  The multi-task / packed kernels keep
+// three blocks more: the packed range of a wavefront ends behind its longest task, rounded up to a group, and a strip of the last group
+// writes the direction words of the whole group (run_octo, run_pair)
+static u64 dir_words_for(int kid, u64 X, u64 band)
+{
+    const u64 Y = 2 * band + 1;
+    if (kid == K_WIDE) return X * Y;
+    const u64 C = (u64)kernel_cols(kid), LE = (Y - 1) / C;
+    const u64 extra = (kid == K_P17_CE4 || kid == K_O19_CE15 || kid == K_Q19_CE15 || kid == K_Q19_CE15_N) ? 3 : 0;
+    return ((X - 1 + LE) / 16 + 1 + extra) * (u64)kernel_dir_block_words(kid);
+}
+// the tuned kernels take one band each (pick_kernel): 0 = any band (the generic and the wide kernels)
+static u32 kernel_band(int kid)
+{
+    switch (kid) {
+    case K_C17_CE4: case K_C17_CE4_N: case K_P17_CE4: return 512;
+    case K_C5_CE0: case K_C5_CE0_N: case K_O19_CE15: case K_Q19_CE15: case K_Q19_CE15_N: return 150;
+    default: return 0;
+    }
+}
+
 static int pick_kernel(int band, bool has_n)
 {
     if (band == 512) return has_n ? K_C17_CE4_N : K_C17_CE4;
@@ -392,7 +413,6 @@ static int prepare_task(const ITask& it, Prepared& pr)
     u64 X = 0;
     const int st = preflight(alen, blen, band, it.begin_a, it.end_a, it.begin_b, it.end_b, fs, fe, &X, &pr.cells);
     if (st != GAMDP_ST_OK) return st;
-    const u64 Y = 2 * band + 1;
     // GAMDP_DIAG_FORCE_N (diagnostics build only): run N-free inputs through the N-aware kernels as well
     // N by window, not by contig: the DP touches a[begin_a - band .. begin_a + X - 1 + band] and b[begin_b .. begin_b + X - 1] (pos =
     // begin_a - band + x + y, banded_smith_waterman.cc:135-171), the walk stays inside them; 64 bases of margin on either side.
@@ -410,13 +430,7 @@ static int prepare_task(const ITask& it, Prepared& pr)
         has_n = it.sa->window_has_n(it.a_id, it.a_rc, it.a_off, (int64_t)it.begin_a - (int64_t)band - margin, (int64_t)it.begin_a + (int64_t)X - 1 + (int64_t)band + margin) ||
                 it.sb->window_has_n(it.b_id, it.b_rc, it.b_off, (int64_t)it.begin_b - margin, (int64_t)it.begin_b + (int64_t)X - 1 + margin);
     pr.kid = pick_kernel((int)band, has_n);
-    if (pr.kid == K_WIDE) pr.dir_words = X * Y;   // the whole band matrix as int32 (gamdp_wide.hip)
-    else {
-        const int C = kernel_cols(pr.kid);
-        const int LE = (int)((Y - 1) / (u64)C);
-        const u64 nblk = (X - 1 + (u64)LE) / 16 + 1;
-        pr.dir_words = nblk * (u64)kernel_dir_block_words(pr.kid);
-    }
+    pr.dir_words = dir_words_for(pr.kid, X, band);   // (of the kernel picked here: the planner sizes a group that moves to a multi-task kernel by dir_words_for itself)
     DevTask& d = pr.dt;
     const DevSeq& da = it.a_rc ? it.sa->rc[it.a_id] : it.sa->fwd[it.a_id];
     const DevSeq& db = it.b_rc ? it.sb->rc[it.b_id] : it.sb->fwd[it.b_id];
@@ -448,7 +462,7 @@ void fill_result(const DevResult& r, u64 cells, gamdp_result& o)
 
 // ---- L0 batch -----------------------------------------------------------------------------------
 
-int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops* ops)
+int Ctx::align(const TaskSrc& tasks, size_t n, gamdp_result* out, const gamdp_ops* ops)
 {
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return GAMDP_EHIP; }
     if (n == 0) return 0;
@@ -465,7 +479,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         parallel_for(n, [&](size_t lo, size_t hi) {
             bool rc_seen = false;
             for (size_t ti = lo; ti < hi; ti++) {
-                const ITask& t = tasks[ti];
+                const ITask t = tasks[ti];
                 const bool bad = t.band > GAMDP_MAX_BAND || t.a_id >= t.sa->lens.size() || t.b_id >= t.sb->lens.size() ||
                                  (t.a_rc && !t.sa->has_codes()) || (t.b_rc && !t.sb->has_codes());
                 if (bad) { size_t cur = bad_at.load(); while (ti < cur && !bad_at.compare_exchange_weak(cur, ti)) {} break; }
@@ -474,14 +488,14 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             if (rc_seen) any_rc.store(true);
         });
         if (bad_at.load() < n) {
-            const ITask& t = tasks[bad_at.load()];
+            const ITask t = tasks[bad_at.load()];
             if (t.band > GAMDP_MAX_BAND) { set_error("band " + std::to_string(t.band) + " exceeds GAMDP_MAX_BAND"); return GAMDP_ENOTSUP; }
             if (t.a_id >= t.sa->lens.size() || t.b_id >= t.sb->lens.size()) { set_error("sequence id out of range"); return GAMDP_EINVAL; }
             set_error("reverse complement requested on a packed-only (synthetic) sequence set"); return GAMDP_EINVAL;
         }
         if (any_rc.load()) {
             for (size_t ti = 0; ti < n; ti++) {
-                const ITask& t = tasks[ti];
+                const ITask t = tasks[ti];
                 if (t.a_rc) add(t.sa, t.a_id);
                 if (t.b_rc) add(t.sb, t.b_id);
             }
@@ -528,6 +542,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
     mark("pre-checks");
     // (the per-kernel task lists and the sort's scratch keep their memory from call to call: freeing and re-allocating half a megabyte
     // per call goes through mmap / munmap, and an munmap interrupts every thread of the host pool)
+    u64 rows_of[K_COUNT] = {0};   // rows of the tasks of every kernel's group
     if (w_groups.size() != (size_t)K_COUNT) w_groups.resize(K_COUNT);
     std::vector<std::vector<u32>>& groups = w_groups;
     for (auto& gv : groups) gv.clear();
@@ -542,10 +557,34 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         }
     }
     {
-        size_t per_kid[K_COUNT] = {0};
-        for (size_t i = 0; i < n; i++) if (kidv[i] >= 0) per_kid[kidv[i]]++;
-        for (int k = 0; k < K_COUNT; k++) groups[k].reserve(per_kid[k]);
-        for (size_t i = 0; i < n; i++) if (kidv[i] >= 0) groups[kidv[i]].push_back((u32)i);
+        // (how many tasks and how many rows each kernel got: counted by the parts of a parallel loop -- every serial pass over 100 000
+        // tasks is 0.1 ms in front of the launch)
+        // P chunks of the task list count, one thread turns the counts into places, the chunks fill: every group in ascending task order
+        const size_t P = n >= 32768 ? 16 : 1;
+        auto chunk = [&](size_t c) { return n * c / P; };
+        auto on_chunks = [&](auto&& fn) {
+            if (P == 1) { fn((size_t)0); return; }
+            auto body = [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) fn(c); };
+            HostPool::get().run(P, body);
+        };
+        std::vector<size_t> cnt(P * K_COUNT, 0);
+        std::vector<u64> rws(P * K_COUNT, 0);
+        on_chunks([&](size_t c) {
+            size_t cc[K_COUNT] = {0};   // (on the chunk's own stack: the rows of `cnt` share cache lines)
+            u64 rr[K_COUNT] = {0};
+            for (size_t i = chunk(c); i < chunk(c + 1); i++) if (kidv[i] >= 0) { cc[kidv[i]]++; rr[kidv[i]] += rowsv[i]; }
+            for (int k = 0; k < K_COUNT; k++) { cnt[c * K_COUNT + k] = cc[k]; rws[c * K_COUNT + k] = rr[k]; }
+        });
+        for (int k = 0; k < K_COUNT; k++) {
+            size_t run = 0;
+            for (size_t c = 0; c < P; c++) { const size_t v = cnt[c * K_COUNT + k]; cnt[c * K_COUNT + k] = run; run += v; rows_of[k] += rws[c * K_COUNT + k]; }
+            groups[k].resize(run);
+        }
+        on_chunks([&](size_t c) {
+            size_t at[K_COUNT];
+            for (int k = 0; k < K_COUNT; k++) at[k] = cnt[c * K_COUNT + k];
+            for (size_t i = chunk(c); i < chunk(c + 1); i++) if (kidv[i] >= 0) groups[kidv[i]][at[kidv[i]]++] = (u32)i;
+        });
     }
 
     // Small band-150 batches (merge-block rounds): one launch instead of two.  The launches of a batch run one after the
@@ -558,6 +597,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         auto &f = groups[K_C5_CE0], &a = groups[K_C5_CE0_N];
         if (!keep_split && !f.empty() && !a.empty() && f.size() + a.size() <= (size_t)n_cu * (size_t)kernel_waves_per_cu(K_C5_CE0_N)) {
             for (u32 i : f) { prep[i].kid = K_C5_CE0_N; kidv[i] = (int8_t)K_C5_CE0_N; }
+            rows_of[K_C5_CE0_N] += rows_of[K_C5_CE0]; rows_of[K_C5_CE0] = 0;
             std::vector<u32> all(f.size() + a.size());
             std::merge(f.begin(), f.end(), a.begin(), a.end(), all.begin());   // both ascending: stays ascending
             a.swap(all);
@@ -579,8 +619,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             if (g.empty() || g.size() < std::max<size_t>(thr, 1)) continue;
             // ... and long enough: below ~8 k rows the top / end blocks and the one-after-the-other walks of a
             // wavefront eat what the fill gains (measured: 400 000 x 2 kb pairs 15 % slower, 5 kb equal, 20 kb 8 % faster)
-            u64 rows = 0;
-            for (u32 i : g) rows += (u64)rowsv[i];
+            const u64 rows = rows_of[from[v]];
             // without N and with enough tasks to fill the chip eight at a time: two quads per wavefront, packed f16 (round 3: from
             // ~4 k rows on: 400 000 x 5 kb pairs measured 5 % faster than one task per wavefront, 9 % faster than four)
             // ... and, for long contigs, from 6 144 tasks on: more than the one-task kernel holds in one round (5 120), and a
@@ -602,18 +641,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                               (quad_min >= 0 ? g.size() >= (size_t)quad_min : (tier(16384, 384) || tier(12288, 1024) || tier(8192, 2560) || tier(6144, 4608)));
             if (!octo && quad_min < 0 && rows / g.size() < 8192) continue;
             const int to = octo ? K_O19_CE15 : (v == 0 ? K_Q19_CE15 : K_Q19_CE15_N);
-            const u64 C = (u64)kernel_cols(to);
-            const u64 dbw = (u64)kernel_dir_block_words(to);
-            parallel_for(g.size(), [&](size_t lo, size_t hi) {
-                for (size_t k = lo; k < hi; k++) {
-                    const u32 i = g[k];
-                    const u64 Y = 2 * (u64)prep[i].dt.band + 1, LE = (Y - 1) / C;
-                    prep[i].kid = to;
-                    // (+ 3 blocks: the packed range of a wavefront ends behind its longest task, rounded up to a group, and a strip of the
-                    // last group writes the direction words of the whole group -- run_octo)
-                    prep[i].dir_words = (((u64)prep[i].dt.X - 1 + LE) / 16 + 1 + 3) * dbw;
-                }
-            });
+            // (nothing to rewrite per task: the planner below sizes the slots of a one-band kernel from its longest task)
             groups[to] = std::move(g);
             g.clear();
         }
@@ -626,8 +654,6 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         static const bool no_pair = std::getenv("GAMDP_NO_PAIR") != nullptr;
         auto& g = groups[K_C17_CE4];
         if (!no_pair && !diag_no_dirfree && g.size() >= 2) {
-            const u64 add3 = 3ull * (u64)kernel_dir_block_words(K_P17_CE4);
-            parallel_for(g.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) { const u32 i = g[k]; prep[i].kid = K_P17_CE4; prep[i].dir_words += add3; } });   // same C and LE; + 3 blocks as for the eight-task kernel above
             groups[K_P17_CE4] = std::move(g);
             g.clear();
         }
@@ -656,7 +682,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         auto& g = groups[kid];
         if (g.empty()) continue;
         const u32 max_resident = (u32)n_cu * (u32)kernel_waves_per_cu(kid);
-        sort_by_key_desc(g, cells_key, &w_sort_tmp, &w_sort_count);  // longest tasks first (LPT); ties keep the caller's order
+        // longest tasks first (LPT); ties keep the caller's order.  The tuned kernels take one band each: their tasks' cells are in the order
+        // of their rows, a key of 19 bits at most instead of 40 (two passes of the radix sort instead of three)
+        if (kid <= K_Q19_CE15_N) sort_by_key_desc(g, rowsv, &w_sort_tmp, &w_sort_count);
+        else sort_by_key_desc(g, cells_key, &w_sort_tmp, &w_sort_count);
         // One launch per group if slots sized for its largest direction matrix leave enough resident
         // waves; otherwise peel off the tasks with big matrices into their own launch and retry.
         std::vector<std::vector<u32>> work;
@@ -664,9 +693,10 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
         while (!work.empty()) {
             std::vector<u32> cur = std::move(work.back());
             work.pop_back();
-            u32 maxband = 0;
+            u32 maxband = kernel_band(kid);
             u64 maxdir = 0;
-            {   // (a reduction over the descriptors in sorted -- i.e. random -- order: in parallel for big launches)
+            if (maxband != 0) maxdir = dir_words_for(kid, rowsv[cur[0]], maxband);   // a one-band kernel: the list is sorted by rows, the longest task first
+            else {   // (a reduction over the descriptors in sorted -- i.e. random -- order: in parallel for big launches)
                 std::mutex red;
                 parallel_for(cur.size(), [&](size_t lo, size_t hi) {
                     u32 mb = 0; u64 md = 0;
@@ -675,6 +705,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
                     maxband = std::max(maxband, mb); maxdir = std::max(maxdir, md);
                 });
             }
+            const u32 one_band = kernel_band(kid);
             const u32 ypad = ((2 * maxband + 2 + 63) / 64) * 64;
             const u64 dirw = ((maxdir + 63) / 64) * 64;
             // the tuned N-free kernels fill their fast blocks without directions and keep, per 4 blocks, one live row
@@ -694,7 +725,7 @@ int Ctx::align(const ITask* tasks, size_t n, gamdp_result* out, const gamdp_ops*
             const u64 want = std::min<u64>((cur.size() + tpw - 1) / tpw, max_resident);
             if (fit < want && cur.size() > 1) {
                 std::vector<u32> big, small;
-                for (u32 i : cur) (prep[i].dir_words * 2 >= maxdir ? big : small).push_back(i);
+                for (u32 i : cur) ((one_band ? dir_words_for(kid, rowsv[i], one_band) : prep[i].dir_words) * 2 >= maxdir ? big : small).push_back(i);
                 if (!small.empty()) {
                     work.push_back(std::move(small));
                     work.push_back(std::move(big));  // processed first (largest tasks first)
@@ -1071,21 +1102,11 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     const auto t_call = std::chrono::steady_clock::now();
     if (c->arena_budget(true) == 0) { c->set_error("hipMemGetInfo failed"); return GAMDP_EHIP; }
     const double ms_arena = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
-    double ms_conv = 0;   // (the calls taken over as ITasks: summed over the pieces)
-    struct CallTimer { std::chrono::steady_clock::time_point t0; size_t n; const double *arena, *conv; ~CallTimer() { if (diag().timing) std::fprintf(stderr, "libgamdp align_batch: %zu calls, %.2f ms in all (arena budget %.2f ms, calls taken over in %.2f ms)\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), *arena, *conv); } } call_timer{t_call, n, &ms_arena, &ms_conv};
+    struct CallTimer { std::chrono::steady_clock::time_point t0; size_t n; const double* arena; ~CallTimer() { if (diag().timing) std::fprintf(stderr, "libgamdp align_batch: %zu calls, %.2f ms in all (arena budget %.2f ms)\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), *arena); } } call_timer{t_call, n, &ms_arena};
     auto run = [&](Ctx* cc, size_t first, size_t cnt) -> int {
-        if (cc->w_tasks.size() < cnt) cc->w_tasks.resize(cnt);
-        std::vector<ITask>& it = cc->w_tasks;
-        const auto t_conv = std::chrono::steady_clock::now();
-        parallel_for(cnt, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; i++) {
-                const gamdp_task& t = tasks[first + i];
-                it[i] = ITask{sa, sb, t.a_id, t.b_id, t.a_off, t.b_off, t.a_rc != 0, t.b_rc != 0, t.force_start != 0,
-                              t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
-            }
-        });
-        ms_conv += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_conv).count();   // (pieces on two threads: approximate)
-        return cc->align(it.data(), cnt, out + first, nullptr);
+        TaskSrc src;   // the caller's array, read in place
+        src.gt = tasks + first; src.sa = sa; src.sb = sb;
+        return cc->align(src, cnt, out + first, nullptr);
     };
     // Very large batches of small calls (hundreds of thousands): validation, sorting, staging and result conversion of the
     // whole batch would sit in front of / behind the kernel (25 ms of a 120 ms step for 400 000 5 kb pairs).  They go
@@ -1139,14 +1160,9 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor
-            if (c->w_tasks.size() < n) c->w_tasks.resize(n);
-            std::vector<ITask>& it = c->w_tasks;
-            for (size_t i = 0; i < n; i++) {
-                const gamdp_task& t = tasks[i];
-                it[i] = ITask{sa, sb, t.a_id, t.b_id, t.a_off, t.b_off, t.a_rc != 0, t.b_rc != 0, t.force_start != 0,
-                              t.force_end != 0, t.band, t.begin_a, t.end_a, t.begin_b, t.end_b};
-            }
-            return c->align(it.data(), n, out, ops);
+            TaskSrc src;
+            src.gt = tasks; src.sa = sa; src.sb = sb;
+            return c->align(src, n, out, ops);
         }
         return run(c, 0, n);
     }

@@ -24,6 +24,18 @@ static long check(size_t n_keys, size_t n_ids, uint64_t mask, uint64_t seed)
     return ids == want ? 0 : 1;
 }
 
+static long check32(size_t n, uint32_t mask, uint64_t seed)   // 32-bit keys (the rows of a task): the planner's key for one-band kernels
+{
+    std::vector<uint32_t> key(n), ids(n);
+    for (size_t i = 0; i < n; i++) { key[i] = (uint32_t)rnd(seed) & mask; ids[i] = (uint32_t)i; }
+    std::vector<uint32_t> want = ids;
+    std::stable_sort(want.begin(), want.end(), [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
+    std::vector<uint32_t> tmp;
+    std::vector<size_t> cnt;
+    gamdp::sort_by_key_desc(ids, key, &tmp, &cnt);   // (with the caller's scratch, as the planner calls it)
+    return ids == want ? 0 : 1;
+}
+
 int main()
 {
     std::atomic<long> bad{0};
@@ -31,6 +43,8 @@ int main()
     const uint64_t masks[] = {0x3ffull, 0x1fffffull, 0xffffffffffull, 0x7ull, 0x0ull};
     for (size_t n : sizes)
         for (uint64_t m : masks) bad += check(n + n / 3 + 5, n, m, 0x9E3779B97F4A7C15ull ^ (n * 31 + m));
+    for (size_t n : {(size_t)5000, (size_t)40000, (size_t)100000})
+        for (uint32_t m : {0x7fffu, 0x7ffffu, 0xffu, 0xffffffffu}) bad += check32(n, m, 1234567 + n + m);
     // several callers at once
     std::vector<std::thread> th;
     for (unsigned k = 0; k < 4; ++k) th.emplace_back([&, k] { for (int rep = 0; rep < 4; ++rep) bad += check(150000, 100000 + 1000 * k, 0x1ffffffffull, 77 + 13 * k + rep); });
