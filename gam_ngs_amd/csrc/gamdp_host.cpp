@@ -1151,12 +1151,18 @@ int gamdp_align_batch(gamdp_ctx* ctx, const gamdp_seqset* set_a, const gamdp_seq
         const double units_per_piece = (double)n * (7.0 / 24.0) / (b150 ? 8.0 : 2.0);
         const bool one_length = (double)rows_max * (double)std::max<size_t>(1, cnt) <= 1.25 * (double)rows_sum;
         static const double min_rounds_env = [] { const char* e = std::getenv("GAMDP_CHUNK_MIN_ROUNDS"); return e ? std::min(std::max(std::atof(e), 0.0), 1000.0) : -1.0; }();
-        // (round 6, with the host side of a call at half its cost: calls of one length of >= 4 k rows stay whole below three rounds per piece --
-        // 131 072 x 5 kb 29.0 in pieces, 27.3 ms whole; 200 000 x 5 kb 43.8 / 41.6; 400 000 x 5 kb a tie; shorter calls keep half a round:
-        // 400 000 x 2 kb 40.3 / 42.9, 262 144 x 1 kb 18.7 / 22.7, 131 072 x 2 kb 14.6 / 15.7, 300 000 x 3 kb 41.5 / 42.1; tools/ab_chunks_r06.sh)
-        const double rows_avg = (double)rows_sum / (double)std::max<size_t>(1, cnt);
-        const double min_rounds = min_rounds_env >= 0 ? min_rounds_env : (one_length ? (rows_avg >= 4000.0 ? 3.0 : 0.5) : 2.5);
+        // (round 6, with the host side of a call at a third of its cost -- ~1.5 ms per 100 000 calls in front of the launch: pieces pay from
+        // three rounds per piece on whatever the length, and only while the host's share is worth hiding, 5 % of the kernels' time or more:
+        // 400 000 x 2 kb 34.9 ms in pieces / 36.8 whole, x 5 kb 71.7 / 76.2; 300 000 x 3 kb and 200 000 x 2 kb ties; 131 072 x 2 kb 14.2 / 13.2,
+        // 262 144 x 1 kb 18.6 / 17.7, 131 072 x 5 kb and 200 000 x 5 kb whole; 200 000 x 5 kb at band 512 105.0 / 101.6 (host 3 % of its
+        // kernels); tools/ab_chunks_r06.sh, tools/sweep_r06.sh)
+        const double min_rounds = min_rounds_env >= 0 ? min_rounds_env : (one_length ? 3.0 : 2.5);
         if (units_per_piece < min_rounds * 16.0 * (double)c->n_cu) chunked = false;
+        {
+            const double cells_total = est / (double)std::max<size_t>(1, cnt) * (double)n;
+            const double kernel_ms = cells_total / (b150 ? 7.0e9 : 12.0e9), host_ms = (double)n * 1.5e-5;   // (rates of the packed kernels on short calls)
+            if (min_rounds_env < 0 && host_ms < 0.05 * kernel_ms) chunked = false;
+        }
     }
     if (!chunked || (ops && ops->ops_buf) || n < 8) {
         if (ops && ops->ops_buf) {  // edit strings (tests): the single-piece path with the caller's ops descriptor
