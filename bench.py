@@ -14,6 +14,9 @@ with torch.distributed.run; `python bench.py --gpus N` on its own spawns the sam
   --scaling weak              every rank aligns its own P pairs; value = N*P pairs' cells / max-over-ranks time.
 With N > 1 the strong-scaling line also carries a short weak-scaling measurement ("weak": {...}).
 There is no data-path collective in either mode; RCCL only carries the barrier and three timing scalars.
+BENCH_SHARE_GPU=1 (tests/test_gpu_bench_ranks.py): all ranks on GPU 0 over gloo, a bounded scratch arena per rank (--arena-gb) -- the
+N > 1 path on a one-GPU box, not a multi-GPU measurement.  With N > 1 rank 0 compares --verify-pairs pairs of ITS share with the CPU
+path (verified_pairs); cpu_baseline itself, a timing of the host cores, stays an N = 1 record.
 
 The printed JSON line also carries
   roofline        algorithmic HBM bytes (0.2507 B per cell update) of one kernel launch divided by
@@ -28,7 +31,8 @@ The printed JSON line also carries
   band150         the headline's own pairs once more at band 150, gam-merge's live band (N = 1, default workload only):
                   GCUPS, kernel, roofline fraction, and a sample verified against the CPU path like the headline's.
   mixed150        a batch shaped like the live driver's calls (100 000 band-150 calls: random windows, force-flag tails, mixed lengths,
-                  a few contigs with N) through the planner's own choice: GCUPS, the kernel mix the library reports, a verified sample.
+                  a few contigs with N) through the planner's own choice: GCUPS over 8 steps (+ median / min step), the kernel mix the
+                  library reports, the time the GPU was busy (the small N-aware launch runs beside the big one), roofline fractions, a verified sample.
   launch_info     what the library says it launched in the last step (gamdp_ctx_launch_info): roofline.kernel comes from there.
   strong8_proxy   (and strong4_proxy) the share ONE GPU gets of the fixed list in a strong-scaling run at N = 8 (4) --
                   pairs 0, 8, 16, ... -- timed on this GPU: GCUPS and projected_Ngpu_factor = N * gcups / value.  A
