@@ -367,7 +367,8 @@ def test_the_limits_that_remain_for_wide_bands():
 @pytest.mark.parametrize("seed", range(2))
 def test_random_cases_vs_oracle_wide_bands(seed):
     """test_random_cases_vs_oracle for bands beyond the systolic kernels (k_align_w): every status, force flags, N, ragged windows."""
-    cases = _cases.cases(9100 + seed, 300, max_len=400 if seed == 0 else 1500, bands=(544, 600, 1000, 2048))
+    # (seed 1: narrow bands in the same batch -- the wide kernel's launch next to the systolic kernels' in one call)
+    cases = _cases.cases(9100 + seed, 300, max_len=400 if seed == 0 else 1500, bands=(544, 600, 1000, 2048) if seed == 0 else (544, 600, 1000, 2048, 150, 20, 512))
     for want_ops in (True, False):
         res = run_cases(cases, want_ops=want_ops)
         bad = []
@@ -381,6 +382,7 @@ def test_random_cases_vs_oracle_wide_bands(seed):
             n_ok += o.status == O.OK
         assert not bad, bad[:3]
         assert n_ok > 100
+    assert "k_align_w" in {r["kernel"] for r in ctx().launch_info()}
 
 
 def test_empty_batch_and_degenerate_sequences():
