@@ -76,3 +76,34 @@ def test_three_ranks_uneven_share():
     line = run_bench("--scaling", "strong", "--pairs", "100", "--len", "5000", "--verify-pairs", "16", ranks=3)
     check_common(line, 3)
     assert line["config"]["pairs_on_rank0_per_step"] == 34
+
+
+def test_the_nccl_calls_of_the_n_gt_1_branch_on_one_rank():
+    """What the ranks above did over gloo, a real 8-GPU run does over RCCL: a float64 all_reduce (MAX, SUM) of three scalars on the rank's
+    GPU and barriers that name the device.  Two ranks cannot share a GPU under RCCL, so the calls themselves run here on ONE rank
+    (world_size 1, backend "nccl", a child process): the dtype, the ops and the `device_ids` barrier are accepted by this torch / RCCL
+    build and give back what went in -- so that the only thing the first real SCALE run adds is more ranks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:%d', rank=0, world_size=1)\n"
+        "dist.barrier(device_ids=[0]); torch.cuda.synchronize(); dist.barrier(device_ids=[0])\n"
+        "t = torch.tensor([1.5, 51249940.0 * 100000, 0.0], dtype=torch.float64, device='cuda')\n"
+        "a = t.clone(); dist.all_reduce(a, op=dist.ReduceOp.MAX)\n"
+        "b = t.clone(); dist.all_reduce(b, op=dist.ReduceOp.SUM)\n"
+        "assert a.tolist() == t.tolist() and b.tolist() == t.tolist(), (a, b)\n"
+        "assert bench.reduce_step_stats(1.5, 7.0, 0.0, device='cuda') == (1.5, 7.0, 0.0)\n"
+        "dist.barrier(device_ids=[0]); dist.destroy_process_group(); print('NCCL-OK')\n"
+    ) % (ROOT, port)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "NCCL-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
